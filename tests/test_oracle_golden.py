@@ -1,0 +1,113 @@
+"""CPU: the oracle (oracle/) reproduces the golden vectors captured from the reference itself
+(tests/golden/make_golden.py).  This is the pin that lets the GPU parity tests trust the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import tiny_edm, tiny_cls, oracle_net, oracle_cls_cfg, T
+from diffusion_tts_amd.hashing import seed0_scale
+from oracle import sampler as osamp
+from oracle import scorers as oscore
+from oracle.classifier import encoder_unet, count_flops as cls_flops
+from oracle.edm_nets import NetCfg, count_flops as net_flops
+
+torch.set_num_threads(4)
+
+
+@pytest.mark.parametrize('name', ['adm_tiny', 'ddpmpp_tiny'])
+def test_denoiser_forward_matches_reference(golden, manifest, name):
+    cfg, sd = tiny_edm(manifest, name)
+    net = oracle_net(cfg, sd)
+    labels = T(golden['fwd_labels'])
+    for tag in ('hi', 'lo', 'rows'):
+        x, s, D = (T(golden[f'fwd_{name}_{tag}_{k}']) for k in ('x', 'sigma', 'D'))
+        got = net(x, s, labels)
+        assert got.dtype == torch.float32
+        err = (got - D).abs().max().item()
+        assert err < 2e-5 * max(1.0, D.abs().max().item()), (tag, err)
+
+
+def test_hash_scale_table(golden):
+    tab = golden['hash_scale_table']
+    mine = np.array([[[seed0_scale(i, k, n) for n in range(64)] for k in range(4)] for i in range(18)])
+    assert np.array_equal(tab, mine)
+
+
+def test_scorers(golden, manifest):
+    img = T(golden['score_images'])
+    b = oscore.BrightnessOracle()(img, None, torch.zeros(5))
+    assert np.allclose(b.numpy(), golden['score_brightness'], atol=1e-7)
+    cfg, sd = tiny_cls(manifest)
+    ocfg = oracle_cls_cfg(cfg)
+    logits = encoder_unet({k: v for k, v in sd.items()}, ocfg, img.float() / 255.0, torch.zeros(5))
+    assert np.allclose(logits.numpy(), golden['score_cls_logits'], atol=2e-5)
+    sc = oscore.ImageNetOracle(ocfg, sd)(img, T(golden['score_labels']), torch.zeros(5))
+    assert np.allclose(sc.numpy(), golden['score_imagenet'], atol=1e-6)
+    jp = oscore.CompressibilityOracle()(img, None, None)
+    assert np.array_equal(jp.numpy(), golden['score_jpeg'])       # same Pillow build in this image
+
+
+def _run_case(golden, manifest, case):
+    meta = manifest['cases'][case]
+    cfg, sd = tiny_edm(manifest, meta['net'])
+    net = oracle_net(cfg, sd)
+    if meta['scorer'] == 'brightness':
+        scorer = oscore.BrightnessOracle()
+    else:
+        ccfg, csd = tiny_cls(manifest)
+        scorer = oscore.ImageNetOracle(oracle_cls_cfg(ccfg), csd)
+    b = meta['batch']
+    lat, lab = T(golden[f'search_latents{b}']), T(golden[f'search_lab{b}'])
+    method = {'NAIVE': 'naive', 'REJECTION_SAMPLING': 'rejection', 'EPS_GREEDY': 'eps_greedy',
+              'ZERO_ORDER': 'zero_order', 'MCTS': 'mcts', 'BEAM_SEARCH': 'beam'}[meta['method']]
+    np.random.seed(0)
+    res = osamp.search(net, lat, lab, method=method, params=dict(scorer=scorer, **meta['params']), seed=0,
+                       num_steps=meta['num_steps'], S_churn=40, S_min=0.05, S_max=50, S_noise=1.003,
+                       scale_fn=seed0_scale)
+    return meta, net, res
+
+
+@pytest.mark.parametrize('case', ['naive_adm', 'naive_ddpmpp', 'rejection_adm', 'rejection_ddpmpp',
+                                  'epsgreedy_adm_bright', 'epsgreedy_adm_imagenet', 'zeroorder_adm', 'mcts_adm'])
+def test_search_trace_matches_reference(golden, manifest, case):
+    meta, net, res = _run_case(golden, manifest, case)
+    assert net.evals == meta['net_rows']
+    # every scorer call the reference made, in order; the last one is the final-image score
+    n_calls = meta['scorer_calls']
+    mine = res['rewards'] + [res['final_scores']]
+    assert len(mine) == n_calls
+    for j in range(n_calls):
+        ref = golden[f'{case}_score{j}']
+        got = mine[j].reshape(-1).numpy()
+        assert np.allclose(got, ref.reshape(-1), atol=2e-6), (case, j, got, ref)
+    # selected indices: recomputed from the reference's own reward vectors
+    if meta['method'] in ('EPS_GREEDY', 'ZERO_ORDER'):
+        N = meta['params']['N']
+        for j, sel in enumerate(res['selected']):
+            ref_sel = golden[f'{case}_score{j}'].reshape(N, meta['batch']).argmax(axis=0)
+            assert np.array_equal(sel.numpy(), ref_sel), (case, j)
+    if meta['method'] == 'REJECTION_SAMPLING':
+        ref_sel = golden[f'{case}_score0'].reshape(meta['batch'], meta['params']['N']).argmax(axis=1)
+        assert np.array_equal(res['selected'][0].numpy(), ref_sel)
+    # final image (PNG written by the reference, read back): exact, allowing a rare 1-LSB flip at a
+    # truncation boundary
+    ref_img = golden[f'{case}_image']                      # [R, B*R, 3] grid, gridh=1
+    R = ref_img.shape[0]
+    mine_img = res['image'].permute(2, 0, 3, 1).reshape(R, -1, 3).numpy()
+    diff = np.abs(mine_img.astype(int) - ref_img.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3, (case, diff.max(), (diff > 0).mean())
+
+
+def test_beam_is_dead_code_like_the_reference(golden, manifest):
+    assert 'AttributeError' in manifest['cases']['beam_adm']['error']
+    with pytest.raises(AttributeError):
+        _run_case(golden, manifest, 'beam_adm')
+
+
+def test_flop_counters_match_reference_measurement(manifest):
+    adm = net_flops(NetCfg('adm', 64, 3, 1000, 192, [1, 2, 3, 4], 4, 3, [32, 16, 8]))
+    song = net_flops(NetCfg('ddpmpp', 32, 3, 10, 128, [2, 2, 2], 4, 4, [16], 9))
+    cls = cls_flops(oracle_cls_cfg(__import__('diffusion_tts_amd.config', fromlist=['x']).ClassifierConfig()))
+    assert abs(adm['total'] - manifest['adm_imagenet64']['flops']) / manifest['adm_imagenet64']['flops'] < 2e-3
+    assert abs(song['total'] - manifest['ddpmpp_cifar10']['flops']) / manifest['ddpmpp_cifar10']['flops'] < 2e-3
+    assert abs(cls['total'] - manifest['cls_imagenet64']['flops']) / manifest['cls_imagenet64']['flops'] < 2e-3
