@@ -1,0 +1,80 @@
+"""ctypes binding of libdts_hip.so (the C ABI declared in include/dts.h).
+
+There is no CPU fallback: if the HIP library has not been built, or a kernel call fails, this raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdts_hip.so')
+
+DTS_F32, DTS_BF16, DTS_F16 = 0, 1, 2
+
+_p, _i, _f, _d, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [('x1', _p), ('c1', C.c_int32), ('x2', _p), ('c2', C.c_int32), ('w', _p), ('bias', _p),
+                ('bias_nc', _p), ('ld_bias_nc', C.c_int32), ('residual', _p), ('out', _p),
+                ('n', C.c_int32), ('hin', C.c_int32), ('win', C.c_int32), ('cout', C.c_int32),
+                ('ksize', C.c_int32), ('up', C.c_int32), ('out_scale', C.c_float), ('dtype', C.c_int32)]
+
+
+# name -> argtypes (every function returns int status except the three noted below)
+SIGNATURES = {
+    'dts_nchw_to_nhwc': [_p, _p, _i, _i, _i, _i, _i, _p],
+    'dts_nhwc_to_nchw': [_p, _i, _p, _i, _i, _i, _i, _p],
+    'dts_pack_conv_weight': [_p, _p, _i, _i, _i, _i, _i, _p, _p],
+    'dts_conv2d': [C.POINTER(ConvArgs), _p],
+    'dts_conv_in3': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    'dts_conv_out3': [_p, _i, _p, _p, _p, _i, _i, _i, _i, _p],
+    'dts_gn_coef': [_p, _i, _p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _i, _p, _p, _p],
+    'dts_gn_apply': [_p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p],
+    'dts_resample2x': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'dts_attention': [_p, _p, _i, _i, _i, _i, _i, _f, _p],
+    'dts_linear': [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    'dts_pos_embedding': [_p, _p, _p, _i, _i, _i, _p],
+    'dts_edm_precond_in': [_p, _p, _i, _f, _p, _p, _i, _i, _p],
+    'dts_edm_precond_out': [_p, _p, _p, _p, _i, _i, _p],
+    'dts_cast_from_f32': [_p, _p, _i, _i64, _p],
+    'dts_cast_to_f32': [_p, _i, _p, _i64, _p],
+    'dts_heun_xhat': [_p, _i, _i, _p, _i, _d, _p, _i, _i, _p],
+    'dts_heun_euler': [_p, _p, _d, _d, _p, _p, _i64, _p],
+    'dts_heun_correct': [_p, _p, _p, _d, _d, _p, _i64, _p],
+    'dts_quantize_u8': [_p, _i, _p, _i64, _p],
+    'dts_brightness': [_p, _p, _i, _i, _p],
+    'dts_u8_to_unit_f32': [_p, _p, _i64, _p],
+    'dts_attnpool_tokens': [_p, _p, _p, _i, _i, _i, _i, _p],
+    'dts_take_token': [_p, _i, _p, _i, _i, _i, _i, _p],
+    'dts_softmax_gather': [_p, _p, _p, _i, _i, _p],
+    'dts_candidate_noise': [_p, _p, _p, _p, _p, _i, _i, _i, _p],
+    'dts_ddim_candidates': [_p, _p, _p, _p, _p, _i, _f, _f, _f, _i, _i64, _p],
+}
+OTHER = {'dts_version': ([], _i), 'dts_last_error': ([], C.c_char_p), 'dts_gn_ws_floats': ([_i, _i], _i64)}
+
+_lib = None
+
+
+def load():
+    """Loads the library once; raises if it is missing (build it with `python -m diffusion_tts_amd.build`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f'{LIB_PATH} not found: the HIP extension is required (no CPU fallback). '
+                           f'Build it with `python -m diffusion_tts_amd.build` or __graft_entry__.build().')
+    lib = C.CDLL(LIB_PATH)
+    for name, argt in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes, fn.restype = argt, _i
+    for name, (argt, rest) in OTHER.items():
+        fn = getattr(lib, name)
+        fn.argtypes, fn.restype = argt, rest
+    _lib = lib
+    return lib
+
+
+def check(status, what=''):
+    if status != 0:
+        msg = load().dts_last_error().decode(errors='replace')
+        raise RuntimeError(f'libdts_hip {what} failed ({status}): {msg}')

@@ -1,0 +1,319 @@
+// K6: fused self-attention (flash-style, online softmax in f32) on MFMA for gfx950.
+//
+// Replaces edm/training/networks.py:182-184 (qkv split, AttentionOp = softmax(q^T k / sqrt(d)) in f32, einsum with v)
+// and edm/unet.py:355-372 / :388-407 (QKVAttentionLegacy / QKVAttention).  The projections' output channels were
+// regrouped at weight-pack time so qkv is [n][t][ q(heads*d) | k(heads*d) | v(heads*d) ].
+//
+// One block = 4 waves = 64 queries of one (sample, head); K/V tiles of 64 keys staged in LDS (row stride d*es+32 B:
+// conflict-free for both the ds_read_b128 row reads of K and the ds_read_b64_tr_b16 transposed reads of V).
+// Per wave (16 queries), with the query on the MFMA column (lane & 15):
+//   S^T[key][q] = K . Q^T        A = K rows (LDS), B = Q rows (registers, loaded once)
+//   online softmax over keys     lane-local over its 16 accumulators + 2 cross-lane maxima/sums
+//   O^T[d][q]  += V^T . P^T      A = V^T via transposed LDS reads, B = P straight from the S^T accumulators
+// so P never leaves registers and each lane ends up with 4 consecutive channels of its query (vector store).
+#include "dts_common.h"
+
+namespace {
+
+template <typename T> struct AttMma;
+template <> struct AttMma<bf16_t> {
+  static __device__ __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16); }
+};
+template <> struct AttMma<f16_t> {
+  static __device__ __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return f32_to_f16_bits(lo) | (f32_to_f16_bits(hi) << 16); }
+};
+
+struct AttP {
+  const char* qkv; char* out;
+  int n, t, heads, d;
+  float scale_log2e;
+};
+
+// ------------------------------------------------------------------------------------------------
+// 16-bit element types
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
+  constexpr int ES = 2, ROWB = D * ES + 32;        // LDS row stride in bytes
+  constexpr int CH = D / 8;                        // 16-byte chunks per row
+  constexpr int KSTEPS = D / 32;                   // MFMA k-steps for Q.K
+  constexpr int DT = D / 16;                       // output d tiles
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;
+  char* sV = smem + 64 * ROWB;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lq = lane & 15, lg = lane >> 4;
+  const int nh = blockIdx.y, n = nh / p.heads, head = nh - n * p.heads;
+  const int C = p.heads * D;
+  const size_t rowstride = (size_t)3 * C * ES;
+  const char* base = p.qkv + (size_t)n * p.t * rowstride + (size_t)head * D * ES;
+  const int q0 = blockIdx.x * 64 + wid * 16;
+  const int qrow = q0 + lq;
+
+  // Q fragments: B operand, lane holds Q[q][8*(lg + 4s) .. +8]
+  uint4 qf[KSTEPS];
+#pragma unroll
+  for (int s = 0; s < KSTEPS; ++s) {
+    qf[s] = make_uint4(0, 0, 0, 0);
+    if (qrow < p.t) qf[s] = *reinterpret_cast<const uint4*>(base + (size_t)qrow * rowstride + (lg + 4 * s) * 16);
+  }
+  f32x4_t o[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) o[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ntiles = (p.t + 63) / 64;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int key0 = kt * 64;
+    __syncthreads();                                 // previous tile fully consumed
+    for (int idx = tid; idx < 64 * CH; idx += 256) {
+      const int r = idx / CH, c = idx - r * CH;
+      uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+      if (key0 + r < p.t) {
+        const char* g = base + (size_t)(key0 + r) * rowstride + c * 16;
+        kv = *reinterpret_cast<const uint4*>(g + (size_t)C * ES);
+        vv = *reinterpret_cast<const uint4*>(g + (size_t)2 * C * ES);
+      }
+      *reinterpret_cast<uint4*>(sK + r * ROWB + c * 16) = kv;
+      *reinterpret_cast<uint4*>(sV + r * ROWB + c * 16) = vv;
+    }
+    __syncthreads();
+
+    // ---- S^T tiles: 4 x (16 keys x 16 queries)
+    f32x4_t sacc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sacc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {
+        const uint4 ka = *reinterpret_cast<const uint4*>(sK + (j * 16 + lq) * ROWB + (lg + 4 * s) * 16);
+        sacc[j] = AttMma<T>::run(ka, qf[s], sacc[j]);
+      }
+    }
+    // ---- online softmax; lane holds keys key0 + j*16 + lg*4 + r of query lq
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = sacc[j][r] * p.scale_log2e;
+        if (key0 + j * 16 + lg * 4 + r >= p.t) v = -INFINITY;
+        sacc[j][r] = v;
+        tmax = fmaxf(tmax, v);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);          // finite: every tile has >= 1 valid key
+    const float alpha = exp2f(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = exp2f(sacc[j][r] - m_new);
+        sacc[j][r] = e;
+        psum += e;
+      }
+    psum += __shfl_xor(psum, 16, 64);
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[i] *= alpha;
+
+    // ---- O^T += V^T . P^T ; k-slot (lg, e): e<4 -> key 16*(2kk) + 4lg + e ; e>=4 -> key 16*(2kk+1) + 4lg + e-4
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4 pb;
+      pb.x = AttMma<T>::pack2(sacc[2 * kk][0], sacc[2 * kk][1]);
+      pb.y = AttMma<T>::pack2(sacc[2 * kk][2], sacc[2 * kk][3]);
+      pb.z = AttMma<T>::pack2(sacc[2 * kk + 1][0], sacc[2 * kk + 1][1]);
+      pb.w = AttMma<T>::pack2(sacc[2 * kk + 1][2], sacc[2 * kk + 1][3]);
+      // transposed read: lane 4q'+p' of each 16-lane group addresses row q', columns 4p'..4p'+3 of a 4x16 block
+      const int rq = (lane & 15) >> 2, rp = lane & 3;
+      const char* va = sV + (32 * kk + 4 * lg + rq) * ROWB + rp * 8;
+      const char* vb = va + 16 * ROWB;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(va + dt * 32));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vb + dt * 32));
+        uint4 av;
+        av.x = (uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
+        av.y = (uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
+        av.z = (uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
+        av.w = (uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+        o[dt] = AttMma<T>::run(av, pb, o[dt]);
+      }
+    }
+  }
+  // ---- store: lane holds channels dt*16 + lg*4 + r of query lq
+  if (qrow < p.t) {
+    const float inv = 1.f / l_run;
+    T* orow = reinterpret_cast<T*>(p.out) + ((size_t)n * p.t + qrow) * C + head * D;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st1<T>(orow + dt * 16 + lg * 4 + r, o[dt][r] * inv);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// f32 (parity) path: same structure on v_mfma_f32_16x16x4_f32; V needs no transpose (one k per lane group).
+template <int D>
+__global__ __launch_bounds__(256) void attention32_kernel(const AttP p) {
+  constexpr int ES = 4, ROWB = D * ES + 32;
+  constexpr int CH = D / 4;
+  constexpr int KCH = D / 16;                      // 16-byte chunk groups along d for Q.K
+  constexpr int DT = D / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;
+  char* sV = smem + 64 * ROWB;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lq = lane & 15, lg = lane >> 4;
+  const int nh = blockIdx.y, n = nh / p.heads, head = nh - n * p.heads;
+  const int C = p.heads * D;
+  const size_t rowstride = (size_t)3 * C * ES;
+  const char* base = p.qkv + (size_t)n * p.t * rowstride + (size_t)head * D * ES;
+  const int q0 = blockIdx.x * 64 + wid * 16;
+  const int qrow = q0 + lq;
+
+  f32x4_t o[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) o[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  const int ntiles = (p.t + 63) / 64;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int key0 = kt * 64;
+    __syncthreads();
+    for (int idx = tid; idx < 64 * CH; idx += 256) {
+      const int r = idx / CH, c = idx - r * CH;
+      uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+      if (key0 + r < p.t) {
+        const char* g = base + (size_t)(key0 + r) * rowstride + c * 16;
+        kv = *reinterpret_cast<const uint4*>(g + (size_t)C * ES);
+        vv = *reinterpret_cast<const uint4*>(g + (size_t)2 * C * ES);
+      }
+      *reinterpret_cast<uint4*>(sK + r * ROWB + c * 16) = kv;
+      *reinterpret_cast<uint4*>(sV + r * ROWB + c * 16) = vv;
+    }
+    __syncthreads();
+    f32x4_t sacc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sacc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KCH; ++s) {
+      float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (qrow < p.t) qv = *reinterpret_cast<const float4*>(base + (size_t)qrow * rowstride + (lg + 4 * s) * 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 ka = *reinterpret_cast<const float4*>(sK + (j * 16 + lq) * ROWB + (lg + 4 * s) * 16);
+        sacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.x, qv.x, sacc[j], 0, 0, 0);
+        sacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.y, qv.y, sacc[j], 0, 0, 0);
+        sacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.z, qv.z, sacc[j], 0, 0, 0);
+        sacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka.w, qv.w, sacc[j], 0, 0, 0);
+      }
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = sacc[j][r] * p.scale_log2e;
+        if (key0 + j * 16 + lg * 4 + r >= p.t) v = -INFINITY;
+        sacc[j][r] = v;
+        tmax = fmaxf(tmax, v);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = exp2f(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = exp2f(sacc[j][r] - m_new);
+        sacc[j][r] = e;
+        psum += e;
+      }
+    psum += __shfl_xor(psum, 16, 64);
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[i] *= alpha;
+    // O^T[d][q] += sum_key V[key][d] P[key][q]; MFMA step r of key tile j: lane group lg supplies key j*16 + 4lg + r
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const char* vrow = sV + (j * 16 + 4 * lg + r) * ROWB + lq * 4;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const float va = *reinterpret_cast<const float*>(vrow + dt * 64);
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va, sacc[j][r], o[dt], 0, 0, 0);
+        }
+      }
+  }
+  if (qrow < p.t) {
+    const float inv = 1.f / l_run;
+    float* orow = reinterpret_cast<float*>(p.out) + ((size_t)n * p.t + qrow) * C + head * D;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const float4 v = make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+      *reinterpret_cast<float4*>(orow + dt * 16 + lg * 4) = v;
+    }
+  }
+}
+
+template <typename K>
+int launch_att(K kernel, const AttP& p, size_t lds, hipStream_t st) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kernel, dim3((p.t + 63) / 64, p.n * p.heads), dim3(256), lds, st, p);
+  DTS_CHECK_LAUNCH("dts_attention");
+  return DTS_OK;
+}
+
+template <typename T>
+int att16(const AttP& p, hipStream_t st) {
+  const size_t lds = (size_t)2 * 64 * (p.d * 2 + 32);
+  switch (p.d) {
+    case 64: return launch_att(attention16_kernel<T, 64>, p, lds, st);
+    case 128: return launch_att(attention16_kernel<T, 128>, p, lds, st);
+    case 256: return launch_att(attention16_kernel<T, 256>, p, lds, st);
+  }
+  return DTS_ERR_UNSUPPORTED;
+}
+
+int att32(const AttP& p, hipStream_t st) {
+  const size_t lds = (size_t)2 * 64 * (p.d * 4 + 32);
+  switch (p.d) {
+    case 64: return launch_att(attention32_kernel<64>, p, lds, st);
+    case 128: return launch_att(attention32_kernel<128>, p, lds, st);
+    case 256: return launch_att(attention32_kernel<256>, p, lds, st);
+  }
+  return DTS_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int dts_attention(const void* qkv, void* out, int dtype, int n, int t, int heads, int d, float scale, dts_stream s) {
+  DTS_CHECK_ARG(qkv && out, "dts_attention: null pointer");
+  DTS_CHECK_ARG(n > 0 && t > 0 && heads > 0, "dts_attention: bad shape");
+  DTS_CHECK_ARG(d == 64 || d == 128 || d == 256, "dts_attention: head dim %d unsupported (64/128/256)", d);
+  DTS_CHECK_ARG((long long)n * heads <= 65535, "dts_attention: n*heads too large for grid.y");
+  AttP p{(const char*)qkv, (char*)out, n, t, heads, d, scale * 1.4426950408889634f};
+  hipStream_t st = to_stream(s);
+  switch (dtype) {
+    case DTS_F32: return att32(p, st);
+    case DTS_BF16: return att16<bf16_t>(p, st);
+    case DTS_F16: return att16<f16_t>(p, st);
+  }
+  dts_set_error("dts_attention: bad dtype %d", dtype);
+  return DTS_ERR_ARG;
+}

@@ -1,0 +1,271 @@
+// K1/K2/K3: implicit-GEMM convolution on MFMA for gfx950.
+//
+// Replaces torch.nn.functional.conv2d at edm/training/networks.py:87 (3x3 pad 1, and the 1x1 skip /
+// qkv / proj convs :159,:163,:164), the nearest-2x upsample at :82-83 (fused into the gather), the
+// channel concat at :458 (two-source K loop) and the residual add / skip_scale at :178-179,:185-186
+// (epilogue).  Same kernel serves the classifier's convs (edm/unet.py:192,228,236).
+//
+// GEMM view:  D[cout][pixel] = sum_k  W[cout][k] * X[pixel][k],   k = (tap, cin), cin contiguous (NHWC).
+//   A operand = packed weights  (row = cout,  K contiguous)
+//   B operand = activation rows (row = pixel, K contiguous; zero rows outside the image)
+// so a lane's accumulator holds 4 consecutive couts of one pixel -> vector stores into NHWC.
+//
+// Tile: 256 threads = 4 waves; block tile (64*WM couts) x (64*WN pixels), WM*WN = 4; wave tile 64x64
+// = 4x4 MFMA 16x16 tiles; K step = 128 bytes per row (64 bf16/f16, 32 f32).  LDS rows are 128 B with the
+// 16-byte chunk index XOR-swizzled by (row & 7): conflict-free ds_read_b128 fragment reads.
+// Global->register->LDS staging, double-buffered, the next tile's loads issued before the MFMAs of the
+// current one.  f32 mode uses v_mfma_f32_16x16x4_f32 (exact f32 FMA chain) = the parity path.
+#include "dts_common.h"
+
+namespace {
+
+struct ConvP {
+  const char* x1; const char* x2;
+  const char* w;
+  const float* bias;
+  const char* bias_nc;
+  const char* residual;
+  char* out;
+  int c1, c2, cin;
+  int ld_bias_nc;
+  int n, hin, win, hout, wout, cout;
+  int taps;        // 1 or 9
+  int up;
+  int P;           // n*hout*wout
+  int n_ct;        // cout tiles
+  int n_pt;        // pixel tiles
+  float out_scale;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static __device__ __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+  }
+};
+template <> struct Mma<f16_t> {
+  static __device__ __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  // the 16-byte chunk holds 4 consecutive k of this lane's row; MFMA j consumes element j of A and B
+  // (k order inside the 16-wide step is permuted identically for both operands).
+  static __device__ __forceinline__ void run(f32x4_t& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), acc, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+template <typename T, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
+  const char* const p_x1 = kp.x1; const char* const p_x2 = kp.x2; const char* const p_w = kp.w;
+  const int p_c1 = kp.c1, p_c2 = kp.c2, p_cin = kp.cin, p_hin = kp.hin, p_win = kp.win, p_hout = kp.hout, p_wout = kp.wout;
+  const int p_taps = kp.taps, p_up = kp.up, p_P = kp.P, p_cout = kp.cout, p_n_ct = kp.n_ct, p_n_pt = kp.n_pt;
+  constexpr int BM = 64 * WM;              // couts per block
+  constexpr int BN = 64 * WN;              // pixels per block
+  constexpr int EPV = ET<T>::EPV;
+  constexpr int BKE = 8 * EPV;             // K elements per step (128 bytes)
+  constexpr int ES = 16 / EPV;             // element size
+  constexpr int RA = BM / 32;              // A rows per thread
+  constexpr int RB = BN / 32;              // B rows per thread
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  // ---- XCD-aware tile mapping: blocks b, b+8, b+16.. (same XCD under round-robin dispatch) walk the
+  // cout tiles of one pixel tile consecutively, so the activation rows are re-read from that XCD's L2.
+  const int nblk = p_n_ct * p_n_pt;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, j = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int ct = bid % p_n_ct, pt = bid / p_n_ct;
+  const int cm0 = ct * BM, pn0 = pt * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid % WM, wn = wid / WM;
+  const int chunk = tid & 7, r0 = tid >> 3;          // staging: 16-byte chunk, first row
+
+  // ---- per-thread pixel rows of the B tile (fixed for the whole K loop)
+  int pix_n[RB], pix_hw[RB];
+#pragma unroll
+  for (int j = 0; j < RB; ++j) {
+    const int pp = pn0 + r0 + 32 * j;
+    if (pp < p_P) {
+      const int hw = p_hout * p_wout;
+      const int n = pp / hw, rem = pp - n * hw;
+      const int ho = rem / p_wout, wo = rem - ho * p_wout;
+      pix_n[j] = n * p_hin * p_win;
+      pix_hw[j] = (ho << 16) | wo;
+    } else {
+      pix_n[j] = -1;
+      pix_hw[j] = 0;
+    }
+  }
+  const int K = p_taps * p_cin;
+  const int steps_per_tap = p_cin / BKE;
+  const int nk = p_taps * steps_per_tap;
+  const char* wbase = p_w + ((size_t)(cm0 + r0) * K) * ES + chunk * 16;
+
+  int src_pix[RB];                                     // source pixel index (or -1) for the current tap
+  uint4 rb[RB]; uint4 ra0, ra1, ra2, ra3;
+
+#define SET_TAP(tap_)                                                                                         \
+  {                                                                                                           \
+    const int dh_ = (p_taps == 9) ? (tap_) / 3 - 1 : 0, dw_ = (p_taps == 9) ? (tap_) % 3 - 1 : 0;             \
+    _Pragma("unroll") for (int j = 0; j < RB; ++j) {                                                          \
+      const int hu = (pix_hw[j] >> 16) + dh_, wu = (pix_hw[j] & 0xffff) + dw_;                                \
+      const bool ok = pix_n[j] >= 0 && (unsigned)hu < (unsigned)p_hout && (unsigned)wu < (unsigned)p_wout;    \
+      const int hs = p_up ? (hu >> 1) : hu, ws = p_up ? (wu >> 1) : wu;                                       \
+      src_pix[j] = ok ? pix_n[j] + hs * p_win + ws : -1;                                                      \
+    }                                                                                                         \
+  }
+#define LOAD_TILE(ks_, ci0_)                                                                                  \
+  {                                                                                                           \
+    const char* wp = wbase + (size_t)(ks_) * BKE * ES;                                                        \
+    ra0 = *reinterpret_cast<const uint4*>(wp); ra1 = *reinterpret_cast<const uint4*>(wp + (size_t)32 * K * ES); \
+    if (RA > 2) { ra2 = *reinterpret_cast<const uint4*>(wp + (size_t)64 * K * ES); ra3 = *reinterpret_cast<const uint4*>(wp + (size_t)96 * K * ES); } \
+    const char* xb; int cs, cofs;                                                                             \
+    if ((ci0_) < p_c1) { xb = p_x1; cs = p_c1; cofs = (ci0_); } else { xb = p_x2; cs = p_c2; cofs = (ci0_) - p_c1; } \
+    _Pragma("unroll") for (int j = 0; j < RB; ++j) {                                                          \
+      uint4 v = make_uint4(0, 0, 0, 0);                                                                       \
+      if (src_pix[j] >= 0)                                                                                    \
+        v = *reinterpret_cast<const uint4*>(xb + ((size_t)src_pix[j] * cs + cofs) * ES + chunk * 16);         \
+      rb[j] = v;                                                                                              \
+    }                                                                                                         \
+  }
+#define STORE_TILE(buf_)                                                                                      \
+  {                                                                                                           \
+    char* sa_ = smem + (buf_) * (A_BYTES + B_BYTES);                                                          \
+    char* sb_ = sa_ + A_BYTES;                                                                                \
+    *reinterpret_cast<uint4*>(sa_ + swz(r0, chunk)) = ra0; *reinterpret_cast<uint4*>(sa_ + swz(r0 + 32, chunk)) = ra1; \
+    if (RA > 2) { *reinterpret_cast<uint4*>(sa_ + swz(r0 + 64, chunk)) = ra2; *reinterpret_cast<uint4*>(sa_ + swz(r0 + 96, chunk)) = ra3; } \
+    _Pragma("unroll") for (int j = 0; j < RB; ++j)                                                            \
+        *reinterpret_cast<uint4*>(sb_ + swz(r0 + 32 * j, chunk)) = rb[j];                                     \
+  }
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  int tap = 0, ci0 = 0;
+  SET_TAP(0);
+  LOAD_TILE(0, 0);
+  STORE_TILE(0);
+  __syncthreads();
+
+  const int lrow = lane & 15, lq = lane >> 4;
+  for (int ks = 0; ks < nk; ++ks) {
+    const int buf = ks & 1;
+    const bool more = ks + 1 < nk;
+    if (more) {
+      ci0 += BKE;
+      if (ci0 == p_cin) { ci0 = 0; ++tap; SET_TAP(tap); }
+      LOAD_TILE(ks + 1, ci0);
+    }
+    const char* sa = smem + buf * (A_BYTES + B_BYTES) + (wm * 64) * 128;
+    const char* sb = smem + buf * (A_BYTES + B_BYTES) + A_BYTES + (wn * 64) * 128;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      uint4 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq + 4 * s));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const uint4*>(sb + swz(i * 16 + lrow, lq + 4 * s));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
+    }
+    if (more) STORE_TILE(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds couts co..co+3 of pixel pp for each (mt, nt)
+  const T* res = reinterpret_cast<const T*>(kp.residual);
+  const T* bnc = reinterpret_cast<const T*>(kp.bias_nc);
+  T* out = reinterpret_cast<T*>(kp.out);
+  const int hw = p_hout * p_wout;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int pp = pn0 + wn * 64 + nt * 16 + lrow;
+    if (pp >= p_P) continue;
+    const int n = pp / hw;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int co = cm0 + wm * 64 + mt * 16 + lq * 4;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = acc[mt][nt][r];
+        if (kp.bias) t += kp.bias[co + r];
+        if (bnc) t += ld1<T>(bnc + (size_t)n * kp.ld_bias_nc + co + r);
+        if (res) t += ld1<T>(res + (size_t)pp * p_cout + co + r);
+        v[r] = t * kp.out_scale;
+      }
+      T* o = out + (size_t)pp * p_cout + co;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st1<T>(o + r, v[r]);
+    }
+  }
+}
+
+template <typename T, int WM, int WN>
+int launch_conv(const ConvP& p, hipStream_t st) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  ConvP q = p;
+  q.n_ct = p.cout / BM;
+  q.n_pt = (p.P + BN - 1) / BN;
+  const size_t lds = 2 * (size_t)(BM + BN) * 128;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, WM, WN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN>), dim3(q.n_ct * q.n_pt), dim3(256), lds, st, q);
+  DTS_CHECK_LAUNCH("dts_conv2d");
+  return DTS_OK;
+}
+
+template <typename T>
+int conv_dispatch(const ConvP& p, hipStream_t st) {
+  if (p.cout % 128 == 0 && p.P >= 128 * 256) return launch_conv<T, 2, 2>(p, st);
+  return launch_conv<T, 1, 4>(p, st);
+}
+
+}  // namespace
+
+extern "C" int dts_conv2d(const dts_conv_args* a, dts_stream s) {
+  DTS_CHECK_ARG(a != nullptr, "dts_conv2d: null args");
+  DTS_CHECK_ARG(a->x1 && a->w && a->out, "dts_conv2d: null tensor");
+  DTS_CHECK_ARG(a->ksize == 1 || a->ksize == 3, "dts_conv2d: ksize %d", a->ksize);
+  DTS_CHECK_ARG(a->n > 0 && a->hin > 0 && a->win > 0, "dts_conv2d: bad shape");
+  DTS_CHECK_ARG(a->cout > 0 && a->cout % 64 == 0, "dts_conv2d: cout %d must be a multiple of 64", a->cout);
+  DTS_CHECK_ARG(a->c2 == 0 || a->x2 != nullptr, "dts_conv2d: c2 without x2");
+  const int bke = (a->dtype == DTS_F32) ? 32 : 64;
+  DTS_CHECK_ARG(a->c1 > 0 && a->c1 % bke == 0 && a->c2 % bke == 0, "dts_conv2d: channels (%d,%d) must be multiples of %d",
+                a->c1, a->c2, bke);
+  DTS_CHECK_ARG(a->bias_nc == nullptr || a->ld_bias_nc >= a->cout, "dts_conv2d: ld_bias_nc");
+  ConvP p;
+  p.x1 = (const char*)a->x1; p.x2 = (const char*)a->x2; p.w = (const char*)a->w;
+  p.bias = a->bias; p.bias_nc = (const char*)a->bias_nc; p.residual = (const char*)a->residual; p.out = (char*)a->out;
+  p.c1 = a->c1; p.c2 = a->c2; p.cin = a->c1 + a->c2; p.ld_bias_nc = a->ld_bias_nc;
+  p.n = a->n; p.hin = a->hin; p.win = a->win;
+  p.hout = a->up ? 2 * a->hin : a->hin; p.wout = a->up ? 2 * a->win : a->win;
+  DTS_CHECK_ARG(p.hout < 32768 && p.wout < 32768, "dts_conv2d: spatial size too large");
+  p.cout = a->cout; p.taps = a->ksize * a->ksize; p.up = a->up;
+  const long long P = (long long)p.n * p.hout * p.wout;
+  DTS_CHECK_ARG(P < (1ll << 30), "dts_conv2d: too many pixels");
+  p.P = (int)P; p.out_scale = a->out_scale; p.n_ct = p.n_pt = 0;
+  hipStream_t st = to_stream(s);
+  DTS_DISPATCH_DTYPE(a->dtype, return conv_dispatch<T>(p, st));
+  return DTS_OK;
+}

@@ -1,0 +1,127 @@
+// Shared device/host helpers for libdts_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/dts.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+struct bf16_t { uint16_t v; };
+struct f16_t { uint16_t v; };
+
+// ---- error plumbing ---------------------------------------------------------------------------
+void dts_set_error(const char* fmt, ...);
+
+#define DTS_CHECK_ARG(cond, ...)                 \
+  do {                                           \
+    if (!(cond)) {                               \
+      dts_set_error(__VA_ARGS__);                \
+      return DTS_ERR_ARG;                        \
+    }                                            \
+  } while (0)
+
+#define DTS_CHECK_LAUNCH(what)                                              \
+  do {                                                                      \
+    hipError_t e__ = hipGetLastError();                                     \
+    if (e__ != hipSuccess) {                                                \
+      dts_set_error("%s: launch failed: %s", what, hipGetErrorString(e__)); \
+      return DTS_ERR_LAUNCH;                                                \
+    }                                                                       \
+  } while (0)
+
+static inline hipStream_t to_stream(dts_stream s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- element traits -----------------------------------------------------------------------------
+template <typename T> struct ET;
+template <> struct ET<float> {
+  static constexpr int EPV = 4;          // elements per 16-byte vector
+  static constexpr int DT = DTS_F32;
+};
+template <> struct ET<bf16_t> {
+  static constexpr int EPV = 8;
+  static constexpr int DT = DTS_BF16;
+};
+template <> struct ET<f16_t> {
+  static constexpr int EPV = 8;
+  static constexpr int DT = DTS_F16;
+};
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
+  __bf16 h = (__bf16)f;  // RNE, NaN-preserving (v_cvt_pk_bf16_f32)
+  return (uint32_t)__builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ float f16_bits_to_f32(uint32_t b) {
+  return (float)__builtin_bit_cast(_Float16, (uint16_t)b);
+}
+__device__ __forceinline__ uint32_t f32_to_f16_bits(float f) {
+  _Float16 h = (_Float16)f;
+  return (uint32_t)__builtin_bit_cast(uint16_t, h);
+}
+
+template <typename T> __device__ __forceinline__ float ld1(const T* p);
+template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld1<bf16_t>(const bf16_t* p) { return bf16_bits_to_f32(p->v); }
+template <> __device__ __forceinline__ float ld1<f16_t>(const f16_t* p) { return f16_bits_to_f32(p->v); }
+template <typename T> __device__ __forceinline__ void st1(T* p, float f);
+template <> __device__ __forceinline__ void st1<float>(float* p, float f) { *p = f; }
+template <> __device__ __forceinline__ void st1<bf16_t>(bf16_t* p, float f) { p->v = (uint16_t)f32_to_bf16_bits(f); }
+template <> __device__ __forceinline__ void st1<f16_t>(f16_t* p, float f) { p->v = (uint16_t)f32_to_f16_bits(f); }
+
+// unpack a 16-byte vector into EPV floats / pack back
+template <typename T> __device__ __forceinline__ void unpack16(const uint4& v, float* f);
+template <> __device__ __forceinline__ void unpack16<float>(const uint4& v, float* f) {
+  f[0] = __builtin_bit_cast(float, v.x); f[1] = __builtin_bit_cast(float, v.y);
+  f[2] = __builtin_bit_cast(float, v.z); f[3] = __builtin_bit_cast(float, v.w);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& v, float* f) {
+  f[0] = bf16_bits_to_f32(v.x & 0xffffu); f[1] = bf16_bits_to_f32(v.x >> 16);
+  f[2] = bf16_bits_to_f32(v.y & 0xffffu); f[3] = bf16_bits_to_f32(v.y >> 16);
+  f[4] = bf16_bits_to_f32(v.z & 0xffffu); f[5] = bf16_bits_to_f32(v.z >> 16);
+  f[6] = bf16_bits_to_f32(v.w & 0xffffu); f[7] = bf16_bits_to_f32(v.w >> 16);
+}
+template <> __device__ __forceinline__ void unpack16<f16_t>(const uint4& v, float* f) {
+  f[0] = f16_bits_to_f32(v.x & 0xffffu); f[1] = f16_bits_to_f32(v.x >> 16);
+  f[2] = f16_bits_to_f32(v.y & 0xffffu); f[3] = f16_bits_to_f32(v.y >> 16);
+  f[4] = f16_bits_to_f32(v.z & 0xffffu); f[5] = f16_bits_to_f32(v.z >> 16);
+  f[6] = f16_bits_to_f32(v.w & 0xffffu); f[7] = f16_bits_to_f32(v.w >> 16);
+}
+template <typename T> __device__ __forceinline__ uint4 pack16(const float* f);
+template <> __device__ __forceinline__ uint4 pack16<float>(const float* f) {
+  return make_uint4(__builtin_bit_cast(uint32_t, f[0]), __builtin_bit_cast(uint32_t, f[1]),
+                    __builtin_bit_cast(uint32_t, f[2]), __builtin_bit_cast(uint32_t, f[3]));
+}
+template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* f) {
+  return make_uint4(f32_to_bf16_bits(f[0]) | (f32_to_bf16_bits(f[1]) << 16),
+                    f32_to_bf16_bits(f[2]) | (f32_to_bf16_bits(f[3]) << 16),
+                    f32_to_bf16_bits(f[4]) | (f32_to_bf16_bits(f[5]) << 16),
+                    f32_to_bf16_bits(f[6]) | (f32_to_bf16_bits(f[7]) << 16));
+}
+template <> __device__ __forceinline__ uint4 pack16<f16_t>(const float* f) {
+  return make_uint4(f32_to_f16_bits(f[0]) | (f32_to_f16_bits(f[1]) << 16),
+                    f32_to_f16_bits(f[2]) | (f32_to_f16_bits(f[3]) << 16),
+                    f32_to_f16_bits(f[4]) | (f32_to_f16_bits(f[5]) << 16),
+                    f32_to_f16_bits(f[6]) | (f32_to_f16_bits(f[7]) << 16));
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// wave-wide (64 lanes) sum
+template <typename F> __device__ __forceinline__ F wave_sum(F v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// dtype dispatch for host launchers
+#define DTS_DISPATCH_DTYPE(dtype, ...)                                   \
+  switch (dtype) {                                                       \
+    case DTS_F32: { using T = float; __VA_ARGS__; } break;               \
+    case DTS_BF16: { using T = bf16_t; __VA_ARGS__; } break;             \
+    case DTS_F16: { using T = f16_t; __VA_ARGS__; } break;               \
+    default: dts_set_error("bad dtype %d", (int)(dtype)); return DTS_ERR_ARG; \
+  }

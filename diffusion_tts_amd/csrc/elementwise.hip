@@ -1,0 +1,496 @@
+// HBM-bound pieces of the hot path: layout/packing, EDM preconditioning (K8), the fused fp64 Heun/Euler
+// step with churn (K9), uint8 quantisation + brightness reward (K10/K11), embedding MLP bits (K7), the
+// classifier tail (K12), the epsilon-greedy candidate builder (K14) and the DDIM candidate step (K13).
+// Every kernel is a grid-stride loop with consecutive lanes on consecutive addresses.
+#include <stdarg.h>
+#include "dts_common.h"
+
+// ---- error string (thread local) --------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void dts_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* dts_last_error(void) { return g_err; }
+extern "C" int dts_version(void) { return 100; }
+
+namespace {
+
+inline int grid1d(long long total, int block = 256, int cap = 256 * 8) {
+  long long g = (total + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+#define GSL(i, total) for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (total); i += (long long)gridDim.x * blockDim.x)
+
+// ---- layout ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int n, int c, int h, int w) {
+  const long long total = (long long)n * c * h * w;
+  GSL(i, total) {                                           // i indexes dst (NHWC)
+    const int ci = (int)(i % c);
+    long long r = i / c;
+    const int x = (int)(r % w); r /= w;
+    const int y = (int)(r % h);
+    const int ni = (int)(r / h);
+    st1<T>(dst + i, src[(((size_t)ni * c + ci) * h + y) * w + x]);
+  }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int n, int c, int h, int w) {
+  const long long total = (long long)n * c * h * w;
+  GSL(i, total) {                                           // i indexes dst (NCHW)
+    const int x = (int)(i % w);
+    long long r = i / w;
+    const int y = (int)(r % h); r /= h;
+    const int ci = (int)(r % c);
+    const int ni = (int)(r / c);
+    dst[i] = ld1<T>(src + (((size_t)ni * h + y) * w + x) * c + ci);
+  }
+}
+template <typename T>
+__global__ void pack_w_kernel(const float* __restrict__ w, T* __restrict__ dst, int O, int I, int kh, int kw,
+                              const int32_t* __restrict__ perm) {
+  const long long total = (long long)O * I * kh * kw;
+  GSL(i, total) {                                           // dst index: [o][kh][kw][i]
+    const int ii = (int)(i % I);
+    long long r = i / I;
+    const int x = (int)(r % kw); r /= kw;
+    const int y = (int)(r % kh);
+    const int o = (int)(r / kh);
+    const int so = perm ? perm[o] : o;
+    st1<T>(dst + i, w[(((size_t)so * I + ii) * kh + y) * kw + x]);
+  }
+}
+template <typename T>
+__global__ void cast_from_f32_kernel(const float* __restrict__ s, T* __restrict__ d, long long count) {
+  GSL(i, count) st1<T>(d + i, s[i]);
+}
+template <typename T>
+__global__ void cast_to_f32_kernel(const T* __restrict__ s, float* __restrict__ d, long long count) {
+  GSL(i, count) d[i] = ld1<T>(s + i);
+}
+
+// ---- K8: EDM preconditioning (networks.py:655-667; all f32 as the reference) ---------------------------
+__global__ void precond_in_kernel(const double* __restrict__ x, const double* __restrict__ sigma, int nsigma, float sd,
+                                  float* __restrict__ xin, float* __restrict__ coef, int n, int chw) {
+  const long long total = (long long)n * chw;
+  GSL(i, total) {
+    const int ni = (int)(i / chw);
+    const float sg = (float)sigma[nsigma == 1 ? 0 : ni];
+    const float s2 = sg * sg, d2 = sd * sd;
+    const float c_in = 1.0f / sqrtf(d2 + s2);
+    xin[i] = c_in * (float)x[i];
+    if (i - (long long)ni * chw == 0) {
+      coef[ni * 4 + 0] = d2 / (s2 + d2);
+      coef[ni * 4 + 1] = sg * sd / sqrtf(s2 + d2);
+      coef[ni * 4 + 2] = c_in;
+      coef[ni * 4 + 3] = logf(sg) / 4.0f;
+    }
+  }
+}
+__global__ void precond_out_kernel(const double* __restrict__ x, const float* __restrict__ F, const float* __restrict__ coef,
+                                   float* __restrict__ D, int n, int chw) {
+  const long long total = (long long)n * chw;
+  GSL(i, total) {
+    const int ni = (int)(i / chw);
+    D[i] = coef[ni * 4 + 0] * (float)x[i] + coef[ni * 4 + 1] * F[i];
+  }
+}
+
+// ---- K9: Heun / Euler step, fp64 state (edm/main.py:82-96) ---------------------------------------------
+template <typename E>
+__global__ void heun_xhat_kernel(const double* __restrict__ x_cur, int xb, int bcast, const E* __restrict__ eps, double coef,
+                                 double* __restrict__ x_hat, int nb, int chw) {
+  const long long total = (long long)nb * chw;
+  const int rep = nb / xb;
+  GSL(i, total) {
+    const int row = (int)(i / chw);
+    const long long e = i - (long long)row * chw;
+    const int src = bcast ? row / rep : row % xb;
+    x_hat[i] = x_cur[(long long)src * chw + e] + coef * (double)eps[i];
+  }
+}
+__global__ void heun_euler_kernel(const double* __restrict__ x_hat, const float* __restrict__ D, double t_hat, double t_next,
+                                  double* __restrict__ d_cur, double* __restrict__ x_next, long long count) {
+  const double dt = t_next - t_hat;
+  GSL(i, count) {
+    const double xh = x_hat[i];
+    const double d = (xh - (double)D[i]) / t_hat;
+    d_cur[i] = d;
+    x_next[i] = xh + dt * d;
+  }
+}
+__global__ void heun_correct_kernel(const double* __restrict__ x_hat, const float* __restrict__ D2, const double* __restrict__ d_cur,
+                                    double t_hat, double t_next, double* __restrict__ x_next, long long count) {
+  const double dt = t_next - t_hat;
+  GSL(i, count) {
+    const double dp = (x_next[i] - (double)D2[i]) / t_next;
+    x_next[i] = x_hat[i] + dt * (0.5 * d_cur[i] + 0.5 * dp);
+  }
+}
+
+// ---- K10/K11 -----------------------------------------------------------------------------------------
+template <typename E>
+__global__ void quantize_kernel(const E* __restrict__ x, uint8_t* __restrict__ out, long long count) {
+  GSL(i, count) {
+    E v = x[i] * (E)127.5 + (E)128;
+    v = v < (E)0 ? (E)0 : (v > (E)255 ? (E)255 : v);
+    out[i] = (uint8_t)v;                                   // truncation, as Tensor.to(torch.uint8)
+  }
+}
+// one block per image; u8/255 in f32, weighted channel sum in f32 (as the reference), spatial mean in f64
+__global__ __launch_bounds__(256) void brightness_kernel(const uint8_t* __restrict__ img, float* __restrict__ rewards, int hw) {
+  __shared__ double red[4];
+  const uint8_t* p = img + (size_t)blockIdx.x * 3 * hw;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < hw; i += blockDim.x) {
+    const float r = (float)p[i] / 255.0f, g = (float)p[hw + i] / 255.0f, b = (float)p[2 * hw + i] / 255.0f;
+    const float lum = r * 0.2126f + g * 0.7152f + b * 0.0722f;
+    acc += (double)lum;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double tot = red[0] + red[1] + red[2] + red[3];
+    float m = (float)(tot / (double)hw);
+    rewards[blockIdx.x] = fminf(fmaxf(m, 0.f), 1.f);
+  }
+}
+__global__ void u8_to_unit_kernel(const uint8_t* __restrict__ img, float* __restrict__ out, long long count) {
+  GSL(i, count) out[i] = (float)img[i] / 255.0f;
+}
+
+// ---- K7 ------------------------------------------------------------------------------------------------
+// one wave per output column; the wave keeps w[n][:] in registers across all m rows
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ y, int ldy, int m, int k,
+                                                      int n, int act_in, int act_out, int accumulate) {
+  const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (col >= n) return;
+  const float* wr = w + (size_t)col * k;
+  for (int row = 0; row < m; ++row) {
+    const float* xr = x + (size_t)row * ldx;
+    float acc = 0.f;
+    for (int j = lane; j < k; j += 64) {
+      float xv = xr[j];
+      if (act_in) xv = silu_f(xv);
+      acc += xv * wr[j];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      float v = acc + (bias ? bias[col] : 0.f);
+      if (act_out) v = silu_f(v);
+      float* o = y + (size_t)row * ldy + col;
+      *o = accumulate ? (*o + v) : v;
+    }
+  }
+}
+__global__ void pos_embedding_kernel(const float* __restrict__ v, const float* __restrict__ freqs, float* __restrict__ out, int n,
+                                     int half, int swap) {
+  const long long total = (long long)n * half;
+  GSL(i, total) {
+    const int ni = (int)(i / half), j = (int)(i - (long long)ni * half);
+    const float a = v[ni] * freqs[j];
+    const float c = cosf(a), s = sinf(a);
+    float* o = out + (size_t)ni * 2 * half;
+    o[j] = swap ? s : c;
+    o[half + j] = swap ? c : s;
+  }
+}
+
+// ---- K12 tail ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attnpool_tokens_kernel(const T* __restrict__ x, const float* __restrict__ pos,
+                                                               T* __restrict__ tok, int hw, int c) {
+  const int n = blockIdx.x;
+  const T* xs = x + (size_t)n * hw * c;
+  T* ts = tok + (size_t)n * (hw + 1) * c;
+  for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+    float sum = 0.f;
+    for (int p = 0; p < hw; ++p) {
+      const float v = ld1<T>(xs + (size_t)p * c + ch);
+      sum += v;
+      st1<T>(ts + (size_t)(p + 1) * c + ch, v + pos[(size_t)ch * (hw + 1) + p + 1]);
+    }
+    st1<T>(ts + ch, sum / (float)hw + pos[(size_t)ch * (hw + 1)]);
+  }
+}
+template <typename T>
+__global__ void take_token_kernel(const T* __restrict__ src, float* __restrict__ out, int n, int t, int c, int token) {
+  const long long total = (long long)n * c;
+  GSL(i, total) {
+    const int ni = (int)(i / c), ch = (int)(i - (long long)ni * c);
+    out[i] = ld1<T>(src + ((size_t)ni * t + token) * c + ch);
+  }
+}
+__global__ __launch_bounds__(256) void softmax_gather_kernel(const float* __restrict__ logits, const int32_t* __restrict__ target,
+                                                              float* __restrict__ rewards, int k) {
+  __shared__ float red[4];
+  __shared__ float bc;
+  const float* row = logits + (size_t)blockIdx.x * k;
+  float mx = -INFINITY;
+  for (int j = threadIdx.x; j < k; j += blockDim.x) mx = fmaxf(mx, row[j]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) bc = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  mx = bc;
+  float sum = 0.f;
+  for (int j = threadIdx.x; j < k; j += blockDim.x) sum += expf(row[j] - mx);
+  sum = wave_sum(sum);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) rewards[blockIdx.x] = expf(row[target[blockIdx.x]] - mx) / (red[0] + red[1] + red[2] + red[3]);
+}
+
+// ---- K14 -----------------------------------------------------------------------------------------------
+// one block per candidate row; fp64 L2 norm by block reduction, then the axpy
+__global__ __launch_bounds__(256) void candidate_noise_kernel(const double* __restrict__ pivot, const double* __restrict__ g,
+                                                               const int32_t* __restrict__ mode, const float* __restrict__ scale,
+                                                               double* __restrict__ cand, int b, int chw) {
+  __shared__ double red[4];
+  const int row = blockIdx.x, cn = row / b, sample = row - cn * b;
+  const double* gr = g + (size_t)row * chw;
+  double* out = cand + (size_t)row * chw;
+  if (mode[cn] == 0) {
+    for (int i = threadIdx.x; i < chw; i += blockDim.x) out[i] = gr[i];
+    return;
+  }
+  double ss = 0.0;
+  for (int i = threadIdx.x; i < chw; i += blockDim.x) ss += gr[i] * gr[i];
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  const double nrm = sqrt(red[0] + red[1] + red[2] + red[3]);
+  const double sc = (double)scale[cn];
+  const double* pv = pivot + (size_t)sample * chw;
+  for (int i = threadIdx.x; i < chw; i += blockDim.x) out[i] = pv[i] + sc * (gr[i] / nrm);
+}
+
+// ---- K13 -----------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void ddim_candidates_kernel(const T* __restrict__ x, const T* __restrict__ e, const T* __restrict__ z, T* __restrict__ prev,
+                                       T* __restrict__ x0_out, float a_t, float a_prev, float sigma_t, int ncand, long long count) {
+  const float sa = sqrtf(a_t), sb = sqrtf(1.f - a_t);
+  const float sp = sqrtf(a_prev), dirc = sqrtf(1.f - a_prev - sigma_t * sigma_t);
+  GSL(i, count) {
+    const float xv = ld1<T>(x + i), ev = ld1<T>(e + i);
+    const float x0 = (xv - sb * ev) / sa;
+    if (x0_out) st1<T>(x0_out + i, x0);
+    const float base = sp * x0 + dirc * ev;
+    for (int c = 0; c < ncand; ++c) {
+      const float zv = z ? ld1<T>(z + (size_t)c * count + i) : 0.f;
+      st1<T>(prev + (size_t)c * count + i, base + sigma_t * zv);
+    }
+  }
+}
+
+}  // namespace
+
+// =========================================================================================================
+#define ST hipStream_t st = to_stream(s)
+
+extern "C" int dts_nchw_to_nhwc(const float* src, void* dst, int dtype, int n, int c, int h, int w, dts_stream s) {
+  DTS_CHECK_ARG(src && dst && n > 0 && c > 0 && h > 0 && w > 0, "dts_nchw_to_nhwc: bad args");
+  ST;
+  const long long total = (long long)n * c * h * w;
+  DTS_DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid1d(total)), dim3(256), 0, st, src, (T*)dst, n, c, h, w);
+    DTS_CHECK_LAUNCH("dts_nchw_to_nhwc");
+  });
+  return DTS_OK;
+}
+extern "C" int dts_nhwc_to_nchw(const void* src, int dtype, float* dst, int n, int c, int h, int w, dts_stream s) {
+  DTS_CHECK_ARG(src && dst && n > 0 && c > 0 && h > 0 && w > 0, "dts_nhwc_to_nchw: bad args");
+  ST;
+  const long long total = (long long)n * c * h * w;
+  DTS_DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), dim3(grid1d(total)), dim3(256), 0, st, (const T*)src, dst, n, c, h, w);
+    DTS_CHECK_LAUNCH("dts_nhwc_to_nchw");
+  });
+  return DTS_OK;
+}
+extern "C" int dts_pack_conv_weight(const float* w, void* dst, int dtype, int O, int I, int kh, int kw, const int32_t* perm,
+                                    dts_stream s) {
+  DTS_CHECK_ARG(w && dst && O > 0 && I > 0 && kh > 0 && kw > 0, "dts_pack_conv_weight: bad args");
+  ST;
+  const long long total = (long long)O * I * kh * kw;
+  DTS_DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL((pack_w_kernel<T>), dim3(grid1d(total)), dim3(256), 0, st, w, (T*)dst, O, I, kh, kw, perm);
+    DTS_CHECK_LAUNCH("dts_pack_conv_weight");
+  });
+  return DTS_OK;
+}
+extern "C" int dts_cast_from_f32(const float* src, void* dst, int dtype, int64_t count, dts_stream s) {
+  DTS_CHECK_ARG(src && dst && count >= 0, "dts_cast_from_f32: bad args");
+  if (count == 0) return DTS_OK;
+  ST;
+  DTS_DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL((cast_from_f32_kernel<T>), dim3(grid1d(count)), dim3(256), 0, st, src, (T*)dst, (long long)count);
+    DTS_CHECK_LAUNCH("dts_cast_from_f32");
+  });
+  return DTS_OK;
+}
+extern "C" int dts_cast_to_f32(const void* src, int dtype, float* dst, int64_t count, dts_stream s) {
+  DTS_CHECK_ARG(src && dst && count >= 0, "dts_cast_to_f32: bad args");
+  if (count == 0) return DTS_OK;
+  ST;
+  DTS_DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL((cast_to_f32_kernel<T>), dim3(grid1d(count)), dim3(256), 0, st, (const T*)src, dst, (long long)count);
+    DTS_CHECK_LAUNCH("dts_cast_to_f32");
+  });
+  return DTS_OK;
+}
+
+extern "C" int dts_edm_precond_in(const double* x, const double* sigma, int nsigma, float sigma_data, float* xin, float* coef, int n,
+                                  int chw, dts_stream s) {
+  DTS_CHECK_ARG(x && sigma && xin && coef && n > 0 && chw > 0, "dts_edm_precond_in: bad args");
+  DTS_CHECK_ARG(nsigma == 1 || nsigma == n, "dts_edm_precond_in: nsigma=%d n=%d", nsigma, n);
+  ST;
+  hipLaunchKernelGGL(precond_in_kernel, dim3(grid1d((long long)n * chw)), dim3(256), 0, st, x, sigma, nsigma, sigma_data, xin, coef, n,
+                     chw);
+  DTS_CHECK_LAUNCH("dts_edm_precond_in");
+  return DTS_OK;
+}
+extern "C" int dts_edm_precond_out(const double* x, const float* F, const float* coef, float* D, int n, int chw, dts_stream s) {
+  DTS_CHECK_ARG(x && F && coef && D && n > 0 && chw > 0, "dts_edm_precond_out: bad args");
+  ST;
+  hipLaunchKernelGGL(precond_out_kernel, dim3(grid1d((long long)n * chw)), dim3(256), 0, st, x, F, coef, D, n, chw);
+  DTS_CHECK_LAUNCH("dts_edm_precond_out");
+  return DTS_OK;
+}
+
+extern "C" int dts_heun_xhat(const double* x_cur, int xb, int bcast, const void* eps, int eps_f32, double noise_coef, double* x_hat,
+                             int nb, int chw, dts_stream s) {
+  DTS_CHECK_ARG(x_cur && eps && x_hat && nb > 0 && chw > 0, "dts_heun_xhat: bad args");
+  DTS_CHECK_ARG(xb > 0 && nb % xb == 0, "dts_heun_xhat: nb=%d not a multiple of xb=%d", nb, xb);
+  ST;
+  const int g = grid1d((long long)nb * chw);
+  if (eps_f32)
+    hipLaunchKernelGGL((heun_xhat_kernel<float>), dim3(g), dim3(256), 0, st, x_cur, xb, bcast, (const float*)eps, noise_coef, x_hat, nb,
+                       chw);
+  else
+    hipLaunchKernelGGL((heun_xhat_kernel<double>), dim3(g), dim3(256), 0, st, x_cur, xb, bcast, (const double*)eps, noise_coef, x_hat,
+                       nb, chw);
+  DTS_CHECK_LAUNCH("dts_heun_xhat");
+  return DTS_OK;
+}
+extern "C" int dts_heun_euler(const double* x_hat, const float* D, double t_hat, double t_next, double* d_cur, double* x_next,
+                              int64_t count, dts_stream s) {
+  DTS_CHECK_ARG(x_hat && D && d_cur && x_next && count > 0, "dts_heun_euler: bad args");
+  DTS_CHECK_ARG(t_hat != 0.0, "dts_heun_euler: t_hat == 0");
+  ST;
+  hipLaunchKernelGGL(heun_euler_kernel, dim3(grid1d(count)), dim3(256), 0, st, x_hat, D, t_hat, t_next, d_cur, x_next, (long long)count);
+  DTS_CHECK_LAUNCH("dts_heun_euler");
+  return DTS_OK;
+}
+extern "C" int dts_heun_correct(const double* x_hat, const float* D2, const double* d_cur, double t_hat, double t_next, double* x_next,
+                                int64_t count, dts_stream s) {
+  DTS_CHECK_ARG(x_hat && D2 && d_cur && x_next && count > 0, "dts_heun_correct: bad args");
+  DTS_CHECK_ARG(t_next != 0.0, "dts_heun_correct: t_next == 0 (last step is Euler only)");
+  ST;
+  hipLaunchKernelGGL(heun_correct_kernel, dim3(grid1d(count)), dim3(256), 0, st, x_hat, D2, d_cur, t_hat, t_next, x_next,
+                     (long long)count);
+  DTS_CHECK_LAUNCH("dts_heun_correct");
+  return DTS_OK;
+}
+
+extern "C" int dts_quantize_u8(const void* x, int is_f32, uint8_t* out, int64_t count, dts_stream s) {
+  DTS_CHECK_ARG(x && out && count > 0, "dts_quantize_u8: bad args");
+  ST;
+  if (is_f32)
+    hipLaunchKernelGGL((quantize_kernel<float>), dim3(grid1d(count)), dim3(256), 0, st, (const float*)x, out, (long long)count);
+  else
+    hipLaunchKernelGGL((quantize_kernel<double>), dim3(grid1d(count)), dim3(256), 0, st, (const double*)x, out, (long long)count);
+  DTS_CHECK_LAUNCH("dts_quantize_u8");
+  return DTS_OK;
+}
+extern "C" int dts_brightness(const uint8_t* img, float* rewards, int n, int hw, dts_stream s) {
+  DTS_CHECK_ARG(img && rewards && n > 0 && hw > 0, "dts_brightness: bad args");
+  ST;
+  hipLaunchKernelGGL(brightness_kernel, dim3(n), dim3(256), 0, st, img, rewards, hw);
+  DTS_CHECK_LAUNCH("dts_brightness");
+  return DTS_OK;
+}
+extern "C" int dts_u8_to_unit_f32(const uint8_t* img, float* out, int64_t count, dts_stream s) {
+  DTS_CHECK_ARG(img && out && count > 0, "dts_u8_to_unit_f32: bad args");
+  ST;
+  hipLaunchKernelGGL(u8_to_unit_kernel, dim3(grid1d(count)), dim3(256), 0, st, img, out, (long long)count);
+  DTS_CHECK_LAUNCH("dts_u8_to_unit_f32");
+  return DTS_OK;
+}
+
+extern "C" int dts_linear(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int m, int k, int n, int act_in,
+                          int act_out, int accumulate, dts_stream s) {
+  DTS_CHECK_ARG(x && w && y && m > 0 && k > 0 && n > 0 && ldx >= k && ldy >= n, "dts_linear: bad args");
+  ST;
+  hipLaunchKernelGGL(linear_kernel, dim3((n + 3) / 4), dim3(256), 0, st, x, ldx, w, bias, y, ldy, m, k, n, act_in, act_out, accumulate);
+  DTS_CHECK_LAUNCH("dts_linear");
+  return DTS_OK;
+}
+extern "C" int dts_pos_embedding(const float* v, const float* freqs, float* out, int n, int half, int swap, dts_stream s) {
+  DTS_CHECK_ARG(v && freqs && out && n > 0 && half > 0, "dts_pos_embedding: bad args");
+  ST;
+  hipLaunchKernelGGL(pos_embedding_kernel, dim3(grid1d((long long)n * half)), dim3(256), 0, st, v, freqs, out, n, half, swap);
+  DTS_CHECK_LAUNCH("dts_pos_embedding");
+  return DTS_OK;
+}
+
+extern "C" int dts_attnpool_tokens(const void* x, const float* pos, void* tokens, int dtype, int n, int hw, int c, dts_stream s) {
+  DTS_CHECK_ARG(x && pos && tokens && n > 0 && hw > 0 && c > 0, "dts_attnpool_tokens: bad args");
+  ST;
+  DTS_DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL((attnpool_tokens_kernel<T>), dim3(n), dim3(256), 0, st, (const T*)x, pos, (T*)tokens, hw, c);
+    DTS_CHECK_LAUNCH("dts_attnpool_tokens");
+  });
+  return DTS_OK;
+}
+extern "C" int dts_take_token(const void* src, int dtype, float* out, int n, int t, int c, int token, dts_stream s) {
+  DTS_CHECK_ARG(src && out && n > 0 && c > 0 && token >= 0 && token < t, "dts_take_token: bad args");
+  ST;
+  DTS_DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL((take_token_kernel<T>), dim3(grid1d((long long)n * c)), dim3(256), 0, st, (const T*)src, out, n, t, c, token);
+    DTS_CHECK_LAUNCH("dts_take_token");
+  });
+  return DTS_OK;
+}
+extern "C" int dts_softmax_gather(const float* logits, const int32_t* target, float* rewards, int n, int k, dts_stream s) {
+  DTS_CHECK_ARG(logits && target && rewards && n > 0 && k > 0, "dts_softmax_gather: bad args");
+  ST;
+  hipLaunchKernelGGL(softmax_gather_kernel, dim3(n), dim3(256), 0, st, logits, target, rewards, k);
+  DTS_CHECK_LAUNCH("dts_softmax_gather");
+  return DTS_OK;
+}
+
+extern "C" int dts_candidate_noise(const double* pivot, const double* g, const int32_t* mode, const float* scale, double* cand, int nb,
+                                   int b, int chw, dts_stream s) {
+  DTS_CHECK_ARG(pivot && g && mode && scale && cand, "dts_candidate_noise: null pointer");
+  DTS_CHECK_ARG(nb > 0 && b > 0 && nb % b == 0 && chw > 0, "dts_candidate_noise: nb=%d b=%d", nb, b);
+  ST;
+  hipLaunchKernelGGL(candidate_noise_kernel, dim3(nb), dim3(256), 0, st, pivot, g, mode, scale, cand, b, chw);
+  DTS_CHECK_LAUNCH("dts_candidate_noise");
+  return DTS_OK;
+}
+
+extern "C" int dts_ddim_candidates(const void* x, const void* e, const void* z, void* prev, void* x0_out, int dtype, float alpha_t,
+                                   float alpha_prev, float sigma_t, int ncand, int64_t count, dts_stream s) {
+  DTS_CHECK_ARG(x && e && prev && ncand > 0 && count > 0, "dts_ddim_candidates: bad args");
+  DTS_CHECK_ARG(alpha_t > 0.f && alpha_t <= 1.f && alpha_prev > 0.f && alpha_prev <= 1.f, "dts_ddim_candidates: alphas out of range");
+  DTS_CHECK_ARG(1.f - alpha_prev - sigma_t * sigma_t >= 0.f, "dts_ddim_candidates: sigma_t too large");
+  ST;
+  DTS_DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL((ddim_candidates_kernel<T>), dim3(grid1d(count)), dim3(256), 0, st, (const T*)x, (const T*)e, (const T*)z, (T*)prev,
+                       (T*)x0_out, alpha_t, alpha_prev, sigma_t, ncand, (long long)count);
+    DTS_CHECK_LAUNCH("dts_ddim_candidates");
+  });
+  return DTS_OK;
+}

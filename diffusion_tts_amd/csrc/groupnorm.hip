@@ -1,0 +1,259 @@
+// K4/K5: GroupNorm statistics -> per-(sample,channel) affine coefficients -> fused apply (+SiLU, +2x2 pool).
+//
+// Replaces torch.nn.functional.group_norm at edm/training/networks.py:104-106 together with the SiLU and
+// the adaptive scale/shift around it (:168, :170-175, :182, :460) and edm/unet.py:254-272 (GroupNorm32,
+// scale-shift norm, avg-pool down).  HBM-bound: one read of x for the statistics, one read + one write
+// for the apply.  Deterministic (no float atomics): per-(sample, pixel-split, group) partial sums, then a
+// fixed-order f64 combine, so identical candidate rows produce bit-identical outputs (ties stay ties).
+#include "dts_common.h"
+
+namespace {
+
+constexpr int GN_SPLITS = 32;
+
+// partial[n][split][g][2] = (sum, sumsq) over this split's pixels and the group's channels
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x1, int c1, const T* __restrict__ x2, int c2,
+                                                          int hw, int groups, int splits, float* __restrict__ partial) {
+  constexpr int EPV = ET<T>::EPV;
+  extern __shared__ float sm[];                      // [planes][C][2]
+  const int C = c1 + c2, cg = C / groups;
+  const int nchunk = C / EPV;
+  const int slots = nchunk < 256 ? nchunk : 256;     // chunk slots per pixel plane
+  const int planes = 256 / slots;
+  const int n = blockIdx.y, split = blockIdx.x;
+  const int per = (hw + splits - 1) / splits;
+  const int p0 = split * per, p1 = min(hw, p0 + per);
+  const int tid = threadIdx.x;
+  const int plane = tid / slots, slot = tid - plane * slots;
+  if (plane < planes) {
+    for (int chunk = slot; chunk < nchunk; chunk += slots) {
+      float s[EPV], ss[EPV];
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) s[e] = ss[e] = 0.f;
+      const int c0 = chunk * EPV;
+      const T* base; int cs, co;
+      if (c0 < c1) { base = x1; cs = c1; co = c0; } else { base = x2; cs = c2; co = c0 - c1; }
+      for (int p = p0 + plane; p < p1; p += planes) {
+        const uint4 v = *reinterpret_cast<const uint4*>(base + ((size_t)n * hw + p) * cs + co);
+        float f[EPV];
+        unpack16<T>(v, f);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) { s[e] += f[e]; ss[e] += f[e] * f[e]; }
+      }
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) {
+        sm[(plane * C + c0 + e) * 2 + 0] = s[e];
+        sm[(plane * C + c0 + e) * 2 + 1] = ss[e];
+      }
+    }
+  }
+  __syncthreads();
+  // one thread per group: fixed-order sum over planes and the group's channels
+  for (int g = tid; g < groups; g += 256) {
+    double a = 0.0, b = 0.0;
+    for (int pl = 0; pl < planes; ++pl)
+      for (int c = g * cg; c < (g + 1) * cg; ++c) { a += sm[(pl * C + c) * 2]; b += sm[(pl * C + c) * 2 + 1]; }
+    float* o = partial + (((size_t)n * splits + split) * groups + g) * 2;
+    o[0] = (float)a;     // partial sums over <= a few thousand f32 values; kept in f32 (rel. err ~1e-7)
+    o[1] = (float)b;
+  }
+}
+
+// coef[n][c] = (a, b):  y = x*a + b  ==  ((x-mean)*rstd*gamma + beta) * (1+scale) + shift
+template <typename T>
+__global__ void gn_coef_kernel(const float* __restrict__ partial, int splits, int groups, int C, int hw, float eps,
+                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const T* __restrict__ ss, int ld_ss, float* __restrict__ coef, int n_total) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_total * C) return;
+  const int n = idx / C, c = idx - n * C;
+  const int cg = C / groups, g = c / cg;
+  double a = 0.0, b = 0.0;
+  for (int s = 0; s < splits; ++s) {
+    const float* q = partial + (((size_t)n * splits + s) * groups + g) * 2;
+    a += q[0]; b += q[1];
+  }
+  const double cnt = (double)hw * cg;
+  const double mean = a / cnt;
+  double var = b / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float fm = (float)mean;
+  float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  float A = rstd * ga;
+  float B = be - fm * A;
+  if (ss) {
+    const float sc = 1.f + ld1<T>(ss + (size_t)n * ld_ss + c);
+    const float sh = ld1<T>(ss + (size_t)n * ld_ss + C + c);
+    A = A * sc;
+    B = B * sc + sh;
+  }
+  coef[(size_t)idx * 2 + 0] = A;
+  coef[(size_t)idx * 2 + 1] = B;
+}
+
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1, int c1, const T* __restrict__ x2, int c2,
+                                                        const float* __restrict__ coef, T* __restrict__ out,
+                                                        int n_total, int h, int w, int silu) {
+  constexpr int EPV = ET<T>::EPV;
+  const int C = c1 + c2, nchunk = C / EPV;
+  const int ho = POOL ? h / 2 : h, wo = POOL ? w / 2 : w;
+  const long long total = (long long)n_total * ho * wo * nchunk;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int chunk = (int)(idx % nchunk);
+    long long pix = idx / nchunk;
+    const int xo = (int)(pix % wo); pix /= wo;
+    const int yo = (int)(pix % ho);
+    const int n = (int)(pix / ho);
+    const int c0 = chunk * EPV;
+    const T* base; int cs, co;
+    if (c0 < c1) { base = x1; cs = c1; co = c0; } else { base = x2; cs = c2; co = c0 - c1; }
+    float A[EPV], B[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; e += 2) {
+      const float4 q = *reinterpret_cast<const float4*>(coef + ((size_t)n * C + c0 + e) * 2);
+      A[e] = q.x; B[e] = q.y; A[e + 1] = q.z; B[e + 1] = q.w;
+    }
+    float r[EPV];
+    if (!POOL) {
+      const uint4 v = *reinterpret_cast<const uint4*>(base + (((size_t)n * h + yo) * w + xo) * cs + co);
+      float f[EPV];
+      unpack16<T>(v, f);
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) { const float y = f[e] * A[e] + B[e]; r[e] = silu ? silu_f(y) : y; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) r[e] = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const uint4 v = *reinterpret_cast<const uint4*>(base + (((size_t)n * h + 2 * yo + dy) * w + 2 * xo + dx) * cs + co);
+          float f[EPV];
+          unpack16<T>(v, f);
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) { const float y = f[e] * A[e] + B[e]; r[e] += 0.25f * (silu ? silu_f(y) : y); }
+        }
+    }
+    *reinterpret_cast<uint4*>(out + (((size_t)n * ho + yo) * wo + xo) * C + c0) = pack16<T>(r);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void resample_kernel(const T* __restrict__ x, T* __restrict__ out, int n_total, int h, int w,
+                                                        int c, int mode) {
+  constexpr int EPV = ET<T>::EPV;
+  const int nchunk = c / EPV;
+  const int ho = mode ? 2 * h : h / 2, wo = mode ? 2 * w : w / 2;
+  const long long total = (long long)n_total * ho * wo * nchunk;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int chunk = (int)(idx % nchunk);
+    long long pix = idx / nchunk;
+    const int xo = (int)(pix % wo); pix /= wo;
+    const int yo = (int)(pix % ho);
+    const int n = (int)(pix / ho);
+    uint4 o;
+    if (mode) {
+      o = *reinterpret_cast<const uint4*>(x + (((size_t)n * h + (yo >> 1)) * w + (xo >> 1)) * c + chunk * EPV);
+    } else {
+      float r[EPV];
+#pragma unroll
+      for (int e = 0; e < EPV; ++e) r[e] = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const uint4 v = *reinterpret_cast<const uint4*>(x + (((size_t)n * h + 2 * yo + dy) * w + 2 * xo + dx) * c + chunk * EPV);
+          float f[EPV];
+          unpack16<T>(v, f);
+#pragma unroll
+          for (int e = 0; e < EPV; ++e) r[e] += 0.25f * f[e];
+        }
+      o = pack16<T>(r);
+    }
+    *reinterpret_cast<uint4*>(out + (((size_t)n * ho + yo) * wo + xo) * c + chunk * EPV) = o;
+  }
+}
+
+inline int gn_splits(int hw) {
+  int s = hw / 64;
+  if (s < 1) s = 1;
+  if (s > GN_SPLITS) s = GN_SPLITS;
+  return s;
+}
+
+inline int grid_for(long long total, int block) {
+  long long g = (total + block - 1) / block;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int64_t dts_gn_ws_floats(int n, int groups) { return (int64_t)n * GN_SPLITS * groups * 2; }
+
+extern "C" int dts_gn_coef(const void* x1, int c1, const void* x2, int c2, int dtype, int n, int hw, int groups, float eps,
+                           const float* gamma, const float* beta, const void* scale_shift, int ld_ss,
+                           float* coef, float* ws, dts_stream s) {
+  const int C = c1 + c2;
+  DTS_CHECK_ARG(x1 && coef && ws, "dts_gn_coef: null pointer");
+  DTS_CHECK_ARG(n > 0 && hw > 0 && groups > 0 && C % groups == 0, "dts_gn_coef: C=%d groups=%d", C, groups);
+  DTS_CHECK_ARG(c2 == 0 || x2, "dts_gn_coef: c2 without x2");
+  const int epv = dtype == DTS_F32 ? 4 : 8;
+  DTS_CHECK_ARG(c1 % epv == 0 && c2 % epv == 0, "dts_gn_coef: channels (%d,%d) unsupported", c1, c2);
+  DTS_CHECK_ARG(scale_shift == nullptr || ld_ss >= 2 * C, "dts_gn_coef: ld_ss");
+  const int splits = gn_splits(hw);
+  hipStream_t st = to_stream(s);
+  DTS_DISPATCH_DTYPE(dtype, {
+    const int nchunk = C / ET<T>::EPV;
+    const int planes = 256 / (nchunk < 256 ? nchunk : 256);
+    const size_t lds = (size_t)planes * C * 2 * sizeof(float);
+    hipLaunchKernelGGL((gn_partial_kernel<T>), dim3(splits, n), dim3(256), lds, st, (const T*)x1, c1, (const T*)x2, c2, hw,
+                       groups, splits, ws);
+    DTS_CHECK_LAUNCH("dts_gn_coef(partial)");
+    const int total = n * C;
+    hipLaunchKernelGGL((gn_coef_kernel<T>), dim3((total + 255) / 256), dim3(256), 0, st, ws, splits, groups, C, hw, eps, gamma,
+                       beta, (const T*)scale_shift, ld_ss, coef, n);
+    DTS_CHECK_LAUNCH("dts_gn_coef(coef)");
+  });
+  return DTS_OK;
+}
+
+extern "C" int dts_gn_apply(const void* x1, int c1, const void* x2, int c2, int dtype, const float* coef, void* out, int n, int h,
+                            int w, int silu, int pool, dts_stream s) {
+  const int C = c1 + c2;
+  DTS_CHECK_ARG(x1 && coef && out, "dts_gn_apply: null pointer");
+  DTS_CHECK_ARG(c2 == 0 || x2, "dts_gn_apply: c2 without x2");
+  const int epv = dtype == DTS_F32 ? 4 : 8;
+  DTS_CHECK_ARG(c1 % epv == 0 && c2 % epv == 0, "dts_gn_apply: channels (%d,%d) unsupported", c1, c2);
+  DTS_CHECK_ARG(!pool || (h % 2 == 0 && w % 2 == 0), "dts_gn_apply: pool needs even h,w");
+  hipStream_t st = to_stream(s);
+  const long long total = (long long)n * (pool ? h / 2 : h) * (pool ? w / 2 : w) * (C / epv);
+  DTS_DISPATCH_DTYPE(dtype, {
+    if (pool)
+      hipLaunchKernelGGL((gn_apply_kernel<T, true>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x1, c1, (const T*)x2,
+                         c2, coef, (T*)out, n, h, w, silu);
+    else
+      hipLaunchKernelGGL((gn_apply_kernel<T, false>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x1, c1, (const T*)x2,
+                         c2, coef, (T*)out, n, h, w, silu);
+    DTS_CHECK_LAUNCH("dts_gn_apply");
+  });
+  return DTS_OK;
+}
+
+extern "C" int dts_resample2x(const void* x, void* out, int dtype, int n, int h, int w, int c, int mode, dts_stream s) {
+  DTS_CHECK_ARG(x && out, "dts_resample2x: null pointer");
+  const int epv = dtype == DTS_F32 ? 4 : 8;
+  DTS_CHECK_ARG(c % epv == 0, "dts_resample2x: c=%d", c);
+  DTS_CHECK_ARG(mode == 1 || (h % 2 == 0 && w % 2 == 0), "dts_resample2x: down needs even h,w");
+  hipStream_t st = to_stream(s);
+  const long long total = (long long)n * (mode ? 2 * h : h / 2) * (mode ? 2 * w : w / 2) * (c / epv);
+  DTS_DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL((resample_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x, (T*)out, n, h, w, c, mode);
+    DTS_CHECK_LAUNCH("dts_resample2x");
+  });
+  return DTS_OK;
+}

@@ -1,0 +1,310 @@
+"""Thin tensor-level wrappers over the C ABI (include/dts.h).  PyTorch supplies device memory and the
+current HIP stream; every computation happens in libdts_hip.so.  Inputs must live on the GPU: there is
+no CPU path here (the CPU restatement lives in oracle/ and is test infrastructure only).
+
+Activation tensors are NHWC: shape [n, h, w, c], contiguous, dtype float32 / bfloat16 / float16.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+_DT = {torch.float32: L.DTS_F32, torch.bfloat16: L.DTS_BF16, torch.float16: L.DTS_F16}
+
+
+def dt_code(dtype):
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise ValueError(f'unsupported activation dtype {dtype}')
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t, name='tensor', dtype=None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f'{name} must be a GPU tensor (the HIP path has no CPU fallback)')
+    if not t.is_contiguous():
+        raise ValueError(f'{name} must be contiguous')
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError(f'{name}: expected {dtype}, got {t.dtype}')
+    return t.data_ptr()
+
+
+def _call(name, *args):
+    lib = L.load()
+    L.check(getattr(lib, name)(*args, _stream()), name)
+
+
+# ---- layout / packing ---------------------------------------------------------------------------
+def nchw_to_nhwc(x, dtype):
+    n, c, h, w = x.shape
+    out = torch.empty((n, h, w, c), dtype=dtype, device=x.device)
+    _call('dts_nchw_to_nhwc', _ptr(x, 'x', torch.float32), _ptr(out), dt_code(dtype), n, c, h, w)
+    return out
+
+
+def nhwc_to_nchw(x):
+    n, h, w, c = x.shape
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    _call('dts_nhwc_to_nchw', _ptr(x), dt_code(x.dtype), _ptr(out), n, c, h, w)
+    return out
+
+
+def pack_conv_weight(w, dtype, out_perm=None):
+    """OIHW float32 (device) -> [O][kh][kw][I] in `dtype`; out_perm: int32 device tensor of source rows."""
+    if w.dim() == 3:                      # conv1d weight [O, I, 1]
+        w = w.unsqueeze(-1)
+    w = w.contiguous()
+    O, I, kh, kw = w.shape
+    out = torch.empty((O, kh, kw, I), dtype=dtype, device=w.device)
+    _call('dts_pack_conv_weight', _ptr(w, 'w', torch.float32), _ptr(out), dt_code(dtype), O, I, kh, kw,
+          _ptr(out_perm, 'perm', torch.int32))
+    return out
+
+
+# ---- convolution --------------------------------------------------------------------------------
+def conv2d(x1, w, bias=None, *, x2=None, bias_nc=None, residual=None, up=False, out_scale=1.0, out=None):
+    n, hin, win, c1 = x1.shape
+    c2 = 0 if x2 is None else x2.shape[-1]
+    cout, kh, kw, cin = w.shape
+    if cin != c1 + c2 or kh != kw:
+        raise ValueError(f'conv2d: weight {tuple(w.shape)} does not match inputs ({c1}+{c2})')
+    ho, wo = (2 * hin, 2 * win) if up else (hin, win)
+    if out is None:
+        out = torch.empty((n, ho, wo, cout), dtype=x1.dtype, device=x1.device)
+    a = L.ConvArgs()
+    a.x1, a.c1 = _ptr(x1, 'x1'), c1
+    a.x2, a.c2 = _ptr(x2, 'x2', x1.dtype), c2
+    a.w = _ptr(w, 'w', x1.dtype)
+    a.bias = _ptr(bias, 'bias', torch.float32)
+    a.bias_nc = _ptr(bias_nc, 'bias_nc', x1.dtype)
+    a.ld_bias_nc = 0 if bias_nc is None else bias_nc.shape[-1]
+    a.residual = _ptr(residual, 'residual', x1.dtype)
+    if residual is not None and tuple(residual.shape) != (n, ho, wo, cout):
+        raise ValueError(f'conv2d: residual shape {tuple(residual.shape)} != {(n, ho, wo, cout)}')
+    a.out = _ptr(out, 'out', x1.dtype)
+    a.n, a.hin, a.win, a.cout, a.ksize = n, hin, win, cout, kh
+    a.up, a.out_scale, a.dtype = int(up), float(out_scale), dt_code(x1.dtype)
+    _call('dts_conv2d', C.byref(a))
+    return out
+
+
+def conv_in3(x, w, bias, cout, dtype):
+    """x f32 NCHW [n,3,h,w]; w f32 OIHW [cout,3,3,3] -> NHWC [n,h,w,cout]."""
+    n, c, h, wd = x.shape
+    assert c == 3
+    out = torch.empty((n, h, wd, cout), dtype=dtype, device=x.device)
+    _call('dts_conv_in3', _ptr(x, 'x', torch.float32), _ptr(w, 'w', torch.float32), _ptr(bias, 'bias', torch.float32),
+          _ptr(out), dt_code(dtype), n, h, wd, cout)
+    return out
+
+
+def conv_out3(x, w_ohwi, bias):
+    """x NHWC [n,h,w,c]; w f32 [3,3,3,c] (O,kh,kw,I) -> f32 NCHW [n,3,h,w]."""
+    n, h, wd, c = x.shape
+    out = torch.empty((n, 3, h, wd), dtype=torch.float32, device=x.device)
+    _call('dts_conv_out3', _ptr(x), dt_code(x.dtype), _ptr(w_ohwi, 'w', torch.float32), _ptr(bias, 'bias', torch.float32),
+          _ptr(out), n, h, wd, c)
+    return out
+
+
+# ---- group norm ---------------------------------------------------------------------------------
+def gn_coef(x1, groups, eps, gamma, beta, *, x2=None, scale_shift=None):
+    n, h, w, c1 = x1.shape
+    c2 = 0 if x2 is None else x2.shape[-1]
+    C_ = c1 + c2
+    lib = L.load()
+    ws = torch.empty((lib.dts_gn_ws_floats(n, groups),), dtype=torch.float32, device=x1.device)
+    coef = torch.empty((n, C_, 2), dtype=torch.float32, device=x1.device)
+    _call('dts_gn_coef', _ptr(x1, 'x1'), c1, _ptr(x2, 'x2', x1.dtype), c2, dt_code(x1.dtype), n, h * w, groups, float(eps),
+          _ptr(gamma, 'gamma', torch.float32), _ptr(beta, 'beta', torch.float32),
+          _ptr(scale_shift, 'scale_shift', x1.dtype), 0 if scale_shift is None else scale_shift.shape[-1],
+          _ptr(coef), _ptr(ws))
+    return coef
+
+
+def gn_apply(x1, coef, *, x2=None, silu=True, pool=False):
+    n, h, w, c1 = x1.shape
+    c2 = 0 if x2 is None else x2.shape[-1]
+    ho, wo = (h // 2, w // 2) if pool else (h, w)
+    out = torch.empty((n, ho, wo, c1 + c2), dtype=x1.dtype, device=x1.device)
+    _call('dts_gn_apply', _ptr(x1, 'x1'), c1, _ptr(x2, 'x2', x1.dtype), c2, dt_code(x1.dtype),
+          _ptr(coef, 'coef', torch.float32), _ptr(out), n, h, w, int(silu), int(pool))
+    return out
+
+
+def group_norm(x1, groups, eps, gamma, beta, *, x2=None, scale_shift=None, silu=True, pool=False):
+    return gn_apply(x1, gn_coef(x1, groups, eps, gamma, beta, x2=x2, scale_shift=scale_shift), x2=x2, silu=silu, pool=pool)
+
+
+def resample2x(x, up):
+    n, h, w, c = x.shape
+    ho, wo = (2 * h, 2 * w) if up else (h // 2, w // 2)
+    out = torch.empty((n, ho, wo, c), dtype=x.dtype, device=x.device)
+    _call('dts_resample2x', _ptr(x), _ptr(out), dt_code(x.dtype), n, h, w, c, int(up))
+    return out
+
+
+# ---- attention ----------------------------------------------------------------------------------
+def attention(qkv, heads, scale):
+    """qkv [n, t, 3*heads*d] (q|k|v blocks) -> [n, t, heads*d]."""
+    n, t, c3 = qkv.shape
+    c = c3 // 3
+    d = c // heads
+    out = torch.empty((n, t, c), dtype=qkv.dtype, device=qkv.device)
+    _call('dts_attention', _ptr(qkv), _ptr(out), dt_code(qkv.dtype), n, t, heads, d, float(scale))
+    return out
+
+
+# ---- embedding / preconditioning ----------------------------------------------------------------
+def linear(x, w, bias=None, *, act_in=False, act_out=False, out=None, accumulate=False):
+    m, k = x.shape
+    nn_ = w.shape[0]
+    if out is None:
+        out = torch.empty((m, nn_), dtype=torch.float32, device=x.device)
+    _call('dts_linear', _ptr(x, 'x', torch.float32), x.stride(0) if x.dim() == 2 else k, _ptr(w, 'w', torch.float32),
+          _ptr(bias, 'bias', torch.float32), _ptr(out, 'out', torch.float32), out.shape[-1], m, k, nn_,
+          int(act_in), int(act_out), int(accumulate))
+    return out
+
+
+def pos_embedding(v, freqs, swap=False):
+    n, half = v.shape[0], freqs.shape[0]
+    out = torch.empty((n, 2 * half), dtype=torch.float32, device=v.device)
+    _call('dts_pos_embedding', _ptr(v, 'v', torch.float32), _ptr(freqs, 'freqs', torch.float32), _ptr(out), n, half, int(swap))
+    return out
+
+
+def edm_precond_in(x, sigma, sigma_data):
+    """x f64 NCHW, sigma f64 [1] or [n] -> (c_in*x as f32 NCHW, coef f32 [n,4] = c_skip,c_out,c_in,c_noise)."""
+    n = x.shape[0]
+    chw = x[0].numel()
+    xin = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    coef = torch.empty((n, 4), dtype=torch.float32, device=x.device)
+    _call('dts_edm_precond_in', _ptr(x, 'x', torch.float64), _ptr(sigma, 'sigma', torch.float64), sigma.numel(),
+          float(sigma_data), _ptr(xin), _ptr(coef), n, chw)
+    return xin, coef
+
+
+def edm_precond_out(x, F, coef):
+    n = x.shape[0]
+    D = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _call('dts_edm_precond_out', _ptr(x, 'x', torch.float64), _ptr(F, 'F', torch.float32), _ptr(coef, 'coef', torch.float32),
+          _ptr(D), n, x[0].numel())
+    return D
+
+
+def cast_from_f32(x, dtype):
+    if dtype == torch.float32:
+        return x
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    _call('dts_cast_from_f32', _ptr(x, 'x', torch.float32), _ptr(out), dt_code(dtype), x.numel())
+    return out
+
+
+def cast_to_f32(x):
+    if x.dtype == torch.float32:
+        return x
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    _call('dts_cast_to_f32', _ptr(x), dt_code(x.dtype), _ptr(out), x.numel())
+    return out
+
+
+# ---- Heun step ----------------------------------------------------------------------------------
+def heun_xhat(x_cur, eps, noise_coef, nb, interleave=False):
+    """x_hat[i] = x_cur[src(i)] + noise_coef*eps[i]; x_cur has xb rows, broadcast to nb rows
+    (Tensor.repeat order unless interleave=True = repeat_interleave order)."""
+    xb = x_cur.shape[0]
+    chw = x_cur[0].numel()
+    if eps.dtype not in (torch.float64, torch.float32):
+        raise ValueError('eps must be float64 or float32')
+    if eps.shape[0] != nb:
+        raise ValueError('eps rows != nb')
+    x_hat = torch.empty((nb,) + tuple(x_cur.shape[1:]), dtype=torch.float64, device=x_cur.device)
+    _call('dts_heun_xhat', _ptr(x_cur, 'x_cur', torch.float64), xb, int(interleave), _ptr(eps, 'eps'),
+          int(eps.dtype == torch.float32), float(noise_coef), _ptr(x_hat), nb, chw)
+    return x_hat
+
+
+def heun_euler(x_hat, D, t_hat, t_next):
+    d_cur = torch.empty_like(x_hat)
+    x_next = torch.empty_like(x_hat)
+    _call('dts_heun_euler', _ptr(x_hat, 'x_hat', torch.float64), _ptr(D, 'D', torch.float32), float(t_hat), float(t_next),
+          _ptr(d_cur), _ptr(x_next), x_hat.numel())
+    return d_cur, x_next
+
+
+def heun_correct(x_hat, D2, d_cur, t_hat, t_next, x_next):
+    _call('dts_heun_correct', _ptr(x_hat, 'x_hat', torch.float64), _ptr(D2, 'D2', torch.float32),
+          _ptr(d_cur, 'd_cur', torch.float64), float(t_hat), float(t_next), _ptr(x_next, 'x_next', torch.float64), x_hat.numel())
+    return x_next
+
+
+# ---- scorer plumbing ----------------------------------------------------------------------------
+def quantize_u8(x):
+    if x.dtype not in (torch.float64, torch.float32):
+        raise ValueError('quantize_u8: float64/float32 only')
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    _call('dts_quantize_u8', _ptr(x), int(x.dtype == torch.float32), _ptr(out), x.numel())
+    return out
+
+
+def brightness(img_u8):
+    n, c, h, w = img_u8.shape
+    assert c == 3
+    out = torch.empty((n,), dtype=torch.float32, device=img_u8.device)
+    _call('dts_brightness', _ptr(img_u8, 'img', torch.uint8), _ptr(out), n, h * w)
+    return out
+
+
+def u8_to_unit_f32(img_u8):
+    out = torch.empty(img_u8.shape, dtype=torch.float32, device=img_u8.device)
+    _call('dts_u8_to_unit_f32', _ptr(img_u8, 'img', torch.uint8), _ptr(out), img_u8.numel())
+    return out
+
+
+def attnpool_tokens(x, pos):
+    n, h, w, c = x.shape
+    out = torch.empty((n, h * w + 1, c), dtype=x.dtype, device=x.device)
+    _call('dts_attnpool_tokens', _ptr(x), _ptr(pos, 'pos', torch.float32), _ptr(out), dt_code(x.dtype), n, h * w, c)
+    return out
+
+
+def take_token(x, token):
+    n, t, c = x.shape
+    out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    _call('dts_take_token', _ptr(x), dt_code(x.dtype), _ptr(out), n, t, c, int(token))
+    return out
+
+
+def softmax_gather(logits, target):
+    n, k = logits.shape
+    out = torch.empty((n,), dtype=torch.float32, device=logits.device)
+    _call('dts_softmax_gather', _ptr(logits, 'logits', torch.float32), _ptr(target, 'target', torch.int32), _ptr(out), n, k)
+    return out
+
+
+def candidate_noise(pivot, g, mode, scale):
+    """pivot [b,...] f64, g [N*b,...] f64 (n-major), mode int32 [N], scale f32 [N] -> candidates [N*b,...] f64."""
+    b = pivot.shape[0]
+    nb = g.shape[0]
+    out = torch.empty_like(g)
+    _call('dts_candidate_noise', _ptr(pivot, 'pivot', torch.float64), _ptr(g, 'g', torch.float64),
+          _ptr(mode, 'mode', torch.int32), _ptr(scale, 'scale', torch.float32), _ptr(out), nb, b, pivot[0].numel())
+    return out
+
+
+def ddim_candidates(x, e, z, alpha_t, alpha_prev, sigma_t, want_x0=True):
+    """x, e: [count] tensors (any shape, same dtype); z: [ncand, *x.shape] or None -> (prev [ncand,*], x0)."""
+    ncand = 1 if z is None else z.shape[0]
+    prev = torch.empty((ncand,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+    x0 = torch.empty_like(x) if want_x0 else None
+    _call('dts_ddim_candidates', _ptr(x), _ptr(e, 'e', x.dtype), _ptr(z, 'z', x.dtype), _ptr(prev), _ptr(x0), dt_code(x.dtype),
+          float(alpha_t), float(alpha_prev), float(sigma_t), ncand, x.numel())
+    return prev, x0

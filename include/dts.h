@@ -1,0 +1,153 @@
+/* dts.h -- C ABI of libdts_hip.so, the MI355X (gfx950) kernels under the noise-trajectory-search hot path.
+ *
+ * The reference (rvignav/diffusion-tts) is pure Python on PyTorch: it has NO native code and NO FFI
+ * (SURVEY.md, fact 1).  Each entry point below therefore replaces a *sequence of PyTorch ops* at the
+ * cited reference call site; the Python host (diffusion_tts_amd/) keeps the reference's own module /
+ * function surface on top (INTEGRATION.md shows the binding a maintainer would add).
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative dts_status otherwise; the message is available
+ *    (per thread) from dts_last_error().  Nothing throws across the ABI.
+ *  - all pointers are DEVICE pointers owned by the caller (PyTorch allocations); the library never
+ *    frees or retains them, never allocates on the launch path, never synchronises.
+ *  - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream).
+ *  - activations are NHWC ("channels-last"): [n][h][w][c], element type `dtype`
+ *    (DTS_F32 parity mode, DTS_BF16 / DTS_F16 throughput modes; accumulation is always f32).
+ *  - images/latents at the sampler boundary keep the reference's layout: NCHW, fp64 state
+ *    (edm/main.py:99), fp32 denoiser output (networks.py:667), uint8 scorer input (edm/main.py:126).
+ */
+#ifndef DTS_H_
+#define DTS_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dts_stream;
+
+enum dts_dtype { DTS_F32 = 0, DTS_BF16 = 1, DTS_F16 = 2 };
+enum dts_status { DTS_OK = 0, DTS_ERR_ARG = -1, DTS_ERR_LAUNCH = -2, DTS_ERR_UNSUPPORTED = -3 };
+
+int dts_version(void);
+const char* dts_last_error(void);
+
+/* ---- layout / packing (weight preparation and test plumbing; not on the per-step path) ------------ */
+/* NCHW f32 -> NHWC dtype, and back. */
+int dts_nchw_to_nhwc(const float* src, void* dst, int dtype, int n, int c, int h, int w, dts_stream s);
+int dts_nhwc_to_nchw(const void* src, int dtype, float* dst, int n, int c, int h, int w, dts_stream s);
+/* OIHW f32 conv weight (torch layout, networks.py:62 / unet.py conv_nd) -> [O][kh][kw][I] dtype.
+ * out_perm (device int32[O], nullable): packed row o is taken from source row out_perm[o]; used to
+ * regroup the qkv projection's output channels into q|k|v blocks (networks.py:182, unet.py:365). */
+int dts_pack_conv_weight(const float* w_oihw, void* dst, int dtype, int O, int I, int kh, int kw,
+                         const int32_t* out_perm, dts_stream s);
+
+/* ---- K1/K2/K3: implicit-GEMM convolution on MFMA (networks.py:68-90 Conv2d.forward) --------------- */
+typedef struct dts_conv_args {
+  const void* x1; int32_t c1;     /* input, NHWC [n][hin][win][c1] */
+  const void* x2; int32_t c2;     /* optional 2nd input concatenated on channels (networks.py:458 torch.cat); c2=0 if none */
+  const void* w;                  /* packed weight [cout][ksize*ksize][c1+c2] */
+  const float* bias;              /* [cout] or NULL */
+  const void* bias_nc;            /* per-sample per-channel addend [n][ld_bias_nc] (dtype) or NULL (networks.py:175 x.add_(params)) */
+  int32_t ld_bias_nc;
+  const void* residual;           /* NHWC [n][hout][wout][cout] or NULL (networks.py:178,185) */
+  void* out;                      /* NHWC [n][hout][wout][cout] */
+  int32_t n, hin, win;
+  int32_t cout;
+  int32_t ksize;                  /* 1 or 3 (pad ksize/2, stride 1) */
+  int32_t up;                     /* 1: nearest 2x upsample of the input fused into the gather (networks.py:82-83) */
+  float out_scale;                /* out = (conv + bias + bias_nc + residual) * out_scale  (networks.py:179,186 skip_scale) */
+  int32_t dtype;
+} dts_conv_args;
+int dts_conv2d(const dts_conv_args* a, dts_stream s);
+
+/* first / last convolutions of the U-Nets (3 image channels; direct, not MFMA) */
+/* x f32 NCHW [n][3][h][w] -> out NHWC [n][h][w][cout]; w f32 OIHW [cout][3][3][3] */
+int dts_conv_in3(const float* x, const float* w, const float* bias, void* out, int dtype,
+                 int n, int h, int w_, int cout, dts_stream s);
+/* x NHWC [n][h][w][c] -> out f32 NCHW [n][3][h][w]; w f32 [3][3][3][c] (O,kh,kw,I) */
+int dts_conv_out3(const void* x, int dtype, const float* w, const float* bias, float* out,
+                  int n, int h, int w_, int c, dts_stream s);
+
+/* ---- K4/K5: GroupNorm (+ adaptive scale/shift, SiLU, 2x2 avg-pool) (networks.py:104-106,168-175) -- */
+/* number of floats of workspace dts_gn_coef needs */
+int64_t dts_gn_ws_floats(int n, int groups);
+/* coef[n][C][2] = (a, b) such that groupnorm(x)*gamma+beta [*(1+scale)+shift] == x*a + b.
+ * x = concat(x1, x2) on channels; scale_shift (dtype, [n][ld_ss], scale = [0,C), shift = [C,2C)) may be NULL. */
+int dts_gn_coef(const void* x1, int c1, const void* x2, int c2, int dtype, int n, int hw, int groups, float eps,
+                const float* gamma, const float* beta, const void* scale_shift, int ld_ss,
+                float* coef, float* ws, dts_stream s);
+/* out = act(x*a + b); pool=1 averages 2x2 pixel blocks after the activation (resample filter [1,1],
+ * networks.py:84-85; unet.py:213-215 avg_pool) and writes [n][h/2][w/2][C]. */
+int dts_gn_apply(const void* x1, int c1, const void* x2, int c2, int dtype, const float* coef,
+                 void* out, int n, int h, int w, int silu, int pool, dts_stream s);
+/* 2x resampling of an NHWC tensor for the skip path: mode 0 = 2x2 average (down), 1 = nearest (up). */
+int dts_resample2x(const void* x, void* out, int dtype, int n, int h, int w, int c, int mode, dts_stream s);
+
+/* ---- K6: fused self-attention (networks.py:113-118,181-185; unet.py:355-372,388-407) -------------- */
+/* qkv NHWC-flattened [n][t][3*heads*d] laid out q[heads][d] | k[heads][d] | v[heads][d];
+ * out [n][t][heads*d]; softmax(q.k * scale) in f32. d in {64,128,256}; any t >= 1. */
+int dts_attention(const void* qkv, void* out, int dtype, int n, int t, int heads, int d, float scale, dts_stream s);
+
+/* ---- K7/K8: embedding MLP pieces and EDM preconditioning (networks.py:200-206,437-447,654-668) ---- */
+/* y[m][n] = act_out( act_in(x[m][:]) . w[n][:] + bias[n] ) (+ y if accumulate); all f32; act: 0 none, 1 SiLU */
+int dts_linear(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
+               int m, int k, int n, int act_in, int act_out, int accumulate, dts_stream s);
+/* out[n][0:half] = cos(v[n]*freqs), out[n][half:2half] = sin(..) (swap=1: sin first, networks.py:323) */
+int dts_pos_embedding(const float* v, const float* freqs, float* out, int n, int half, int swap, dts_stream s);
+/* coef[n][4] = (c_skip, c_out, c_in, c_noise) in f32 from sigma (f64, nsigma = 1 or n); xin = c_in * f32(x) */
+int dts_edm_precond_in(const double* x, const double* sigma, int nsigma, float sigma_data,
+                       float* xin, float* coef, int n, int chw, dts_stream s);
+/* D = c_skip*f32(x) + c_out*F  (f32, NCHW) */
+int dts_edm_precond_out(const double* x, const float* F, const float* coef, float* D, int n, int chw, dts_stream s);
+/* f32 -> dtype cast of a dense array (embedding -> activation dtype) and back */
+int dts_cast_from_f32(const float* src, void* dst, int dtype, int64_t count, dts_stream s);
+int dts_cast_to_f32(const void* src, int dtype, float* dst, int64_t count, dts_stream s);
+
+/* ---- K9: fused Heun / Euler ODE step with churn, fp64 state (edm/main.py:82-96) ------------------- */
+/* x_hat[nb] = x_cur[src(i)] + noise_coef * eps[i];  src(i) = i % xb (bcast=0, Tensor.repeat, edm/main.py:803)
+ * or i / (nb/xb) (bcast=1, repeat_interleave, edm/main.py:107).  eps is f64 (eps_f32=0) or f32 (edm/main.py:446). */
+int dts_heun_xhat(const double* x_cur, int xb, int bcast, const void* eps, int eps_f32, double noise_coef,
+                  double* x_hat, int nb, int chw, dts_stream s);
+/* d_cur = (x_hat - D)/t_hat ; x_next = x_hat + (t_next - t_hat)*d_cur */
+int dts_heun_euler(const double* x_hat, const float* D, double t_hat, double t_next,
+                   double* d_cur, double* x_next, int64_t count, dts_stream s);
+/* x_next = x_hat + (t_next - t_hat)*(0.5*d_cur + 0.5*(x_next - D2)/t_next)   (in place on x_next) */
+int dts_heun_correct(const double* x_hat, const float* D2, const double* d_cur, double t_hat, double t_next,
+                     double* x_next, int64_t count, dts_stream s);
+
+/* ---- K10/K11: scorer pre-processing and brightness reward (edm/main.py:126; scorers.py:38-52) ----- */
+/* u8 = trunc(clip(x*127.5+128, 0, 255)); x is f64 (is_f32=0) or f32 */
+int dts_quantize_u8(const void* x, int is_f32, uint8_t* out, int64_t count, dts_stream s);
+/* rewards[n] = clamp(mean_hw(0.2126 R + 0.7152 G + 0.0722 B)/1, 0, 1) on u8/255 images NCHW [n][3][h][w] */
+int dts_brightness(const uint8_t* img, float* rewards, int n, int hw, dts_stream s);
+/* f32 NCHW = u8 / 255.0f (scorers.py:153) */
+int dts_u8_to_unit_f32(const uint8_t* img, float* out, int64_t count, dts_stream s);
+
+/* ---- K12 tail: attention pool + softmax-gather (unet.py:61-69; scorers.py:162-172) ---------------- */
+/* tokens[n][hw+1][c]: token 0 = mean_hw(x) + pos[:,0]; token 1+p = x[n][p] + pos[:,1+p]; pos f32 [c][hw+1] */
+int dts_attnpool_tokens(const void* x, const float* pos, void* tokens, int dtype, int n, int hw, int c, dts_stream s);
+/* out f32 [n][c] = src[n][token][:] */
+int dts_take_token(const void* src, int dtype, float* out, int n, int t, int c, int token, dts_stream s);
+/* rewards[n] = softmax(logits[n][:])[target[n]] */
+int dts_softmax_gather(const float* logits, const int32_t* target, float* rewards, int n, int k, dts_stream s);
+
+/* ---- K14: epsilon-greedy / zero-order candidate-noise builder (edm/main.py:749-800) --------------- */
+/* g: host-drawn standard normals [nb][chw] f64 (uploaded); for row i (candidate n = i / b, sample = i % b):
+ *   mode[n] == 0 : cand[i] = g[i]                                   (fresh Gaussian, edm/main.py:795)
+ *   mode[n] == 1 : cand[i] = pivot[i % b] + (double)scale[n] * (g[i] / ||g[i]||_2)   (edm/main.py:767-788) */
+int dts_candidate_noise(const double* pivot, const double* g, const int32_t* mode, const float* scale,
+                        double* cand, int nb, int b, int chw, dts_stream s);
+
+/* ---- K13: DDIM candidate step, SD backend (scheduling_ddim.py:402-463), eta*std = sigma_t ---------- */
+/* For i in [0,count): x0 = (x - sqrt(1-a_t) e)/sqrt(a_t); [e' = (x - sqrt(a_t) x0)/sqrt(1-a_t) == e];
+ * prev[cand] = sqrt(a_prev) x0 + sqrt(1 - a_prev - sigma_t^2) e + sigma_t z[cand]; ncand candidates share
+ * one (x, e).  f32 math on dtype storage (DTS_F16 as the reference; DTS_F32 for tests). */
+int dts_ddim_candidates(const void* x, const void* e, const void* z, void* prev, void* x0_out, int dtype,
+                        float alpha_t, float alpha_prev, float sigma_t, int ncand, int64_t count, dts_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DTS_H_ */

@@ -1,0 +1,325 @@
+"""GPU parity of every C-ABI kernel against the oracle's primitives (torch CPU fp32/fp64) on seeded inputs.
+f32 mode is the parity path (tight tolerances); bf16/f16 are the throughput modes (tolerance = storage
+rounding of inputs/outputs, accumulation is f32 in both)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import edm_nets as onet          # noqa: E402
+from oracle import classifier as ocls        # noqa: E402
+from oracle import sampler as osamp          # noqa: E402
+from oracle import scorers as oscore         # noqa: E402
+
+DEV = 'cuda'
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2.5e-2, torch.float16: 4e-3}
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from diffusion_tts_amd import ops as o
+    return o
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def rel_err(got, ref):
+    return float((got.double() - ref.double()).abs().max() / max(1e-6, float(ref.double().abs().max())))
+
+
+def to_nhwc(ops, x_nchw, dtype):
+    return ops.nchw_to_nhwc(x_nchw.to(DEV, torch.float32).contiguous(), dtype)
+
+
+def from_nhwc(ops, x):
+    return ops.nhwc_to_nchw(x).cpu()
+
+
+def q(x, dtype):
+    """round-trip through the storage dtype so the CPU reference sees the same inputs."""
+    return x.to(dtype).to(torch.float32)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_layout_roundtrip(ops, dtype):
+    x = torch.randn(2, 24, 5, 7, generator=g(0))
+    y = from_nhwc(ops, to_nhwc(ops, x, dtype))
+    assert torch.equal(y, q(x, dtype))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', ['3x3', '1x1', 'up', 'cat', 'full_epilogue', 'ragged', 'wide'])
+def test_conv2d(ops, dtype, case):
+    gen = g(1)
+    n, h, w, c1, c2, cout, k, up = 2, 8, 8, 64, 0, 64, 3, False
+    if case == '1x1':
+        k = 1
+    if case == 'up':
+        up = True
+    if case == 'cat':
+        c1, c2, k = 128, 64, 1
+    if case == 'ragged':
+        n, h, w = 3, 5, 7                 # 105 pixels: partial pixel tile
+    if case == 'wide':
+        n, h, w, c1, cout = 8, 32, 32, 128, 128          # 8192 pixels: exercises the XCD remap; below 2x2-tile threshold
+    x1 = q(torch.randn(n, c1, h, w, generator=gen), dtype)
+    x2 = q(torch.randn(n, c2, h, w, generator=gen), dtype) if c2 else None
+    wt = q(torch.randn(cout, c1 + c2, k, k, generator=gen) / math.sqrt((c1 + c2) * k * k), dtype)
+    bias = torch.randn(cout, generator=gen)
+    xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+    ref = onet.conv2d(xin, wt, bias, up=up)
+    kw = {}
+    if case == 'full_epilogue':
+        bnc = q(torch.randn(n, cout, generator=gen), dtype)
+        res = q(torch.randn(n, cout, h, w, generator=gen), dtype)
+        ref = (ref + bnc[:, :, None, None] + res) * 0.70710678
+        kw = dict(bias_nc=bnc.to(DEV, dtype), residual=to_nhwc(ops, res, dtype), out_scale=0.70710678)
+    wp = ops.pack_conv_weight(wt.to(DEV), dtype)
+    out = ops.conv2d(to_nhwc(ops, x1, dtype), wp, bias.to(DEV), x2=None if x2 is None else to_nhwc(ops, x2, dtype), up=up, **kw)
+    got = from_nhwc(ops, out)
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) < TOL[dtype], (case, rel_err(got, ref))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_conv2d_big_tiles(ops, dtype):
+    """cout % 128 == 0 and >= 32768 pixels selects the 128x128 block tile."""
+    gen = g(11)
+    n, h, w, c, cout = 8, 64, 64, 64, 128
+    x = q(torch.randn(n, c, h, w, generator=gen), dtype)
+    wt = q(torch.randn(cout, c, 3, 3, generator=gen) / math.sqrt(c * 9), dtype)
+    ref = onet.conv2d(x, wt, None)
+    out = ops.conv2d(to_nhwc(ops, x, dtype), ops.pack_conv_weight(wt.to(DEV), dtype), None)
+    assert rel_err(from_nhwc(ops, out), ref) < TOL[dtype]
+
+
+def test_conv2d_identical_rows_are_bit_identical(ops):
+    """ties must stay ties: the same candidate at different batch positions gives the same bits."""
+    gen = g(2)
+    x = torch.randn(1, 64, 8, 8, generator=gen).repeat(5, 1, 1, 1)
+    wt = torch.randn(64, 64, 3, 3, generator=gen) / 24
+    for dtype in (torch.float32, torch.bfloat16):
+        out = ops.conv2d(to_nhwc(ops, x, dtype), ops.pack_conv_weight(wt.to(DEV), dtype), None)
+        for i in range(1, 5):
+            assert torch.equal(out[0], out[i])
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_conv_in3_out3(ops, dtype):
+    gen = g(3)
+    x = torch.randn(2, 3, 16, 16, generator=gen)
+    w = torch.randn(64, 3, 3, 3, generator=gen) / 5
+    b = torch.randn(64, generator=gen)
+    out = ops.conv_in3(x.to(DEV), w.to(DEV), b.to(DEV), 64, dtype)
+    assert rel_err(from_nhwc(ops, out), onet.conv2d(x, w, b)) < TOL[dtype]
+    y = q(torch.randn(2, 64, 16, 16, generator=gen), dtype)
+    w3 = torch.randn(3, 64, 3, 3, generator=gen) / 24
+    b3 = torch.randn(3, generator=gen)
+    got = ops.conv_out3(to_nhwc(ops, y, dtype), w3.permute(0, 2, 3, 1).contiguous().to(DEV), b3.to(DEV)).cpu()
+    assert rel_err(got, onet.conv2d(y, w3, b3)) < 1e-5
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('variant', ['plain', 'adaptive', 'pool', 'cat', 'nosilu'])
+def test_group_norm(ops, dtype, variant):
+    gen = g(4)
+    n, c, h, w = 3, 192, 8, 8
+    x = q(torch.randn(n, c, h, w, generator=gen) * 2 + 0.5, dtype)
+    gamma, beta = torch.randn(c, generator=gen), torch.randn(c, generator=gen)
+    groups = min(32, c // 4)
+    ref = onet.group_norm(x, gamma, beta, 1e-5)
+    ss = None
+    if variant == 'adaptive':
+        ssv = q(torch.randn(n, 2 * c, generator=gen) * 0.3, dtype)
+        scale, shift = ssv[:, :c, None, None], ssv[:, c:, None, None]
+        ref = torch.addcmul(shift, ref, scale + 1)
+        ss = ssv.to(DEV, dtype)
+    silu = variant != 'nosilu'
+    if silu:
+        ref = onet.silu(ref)
+    if variant == 'pool':
+        ref = onet.resample_down(ref)
+    if variant == 'cat':
+        x1, x2 = to_nhwc(ops, x[:, :128], dtype), to_nhwc(ops, x[:, 128:], dtype)
+    else:
+        x1, x2 = to_nhwc(ops, x, dtype), None
+    out = ops.group_norm(x1, groups, 1e-5, gamma.to(DEV), beta.to(DEV), x2=x2, scale_shift=ss, silu=silu, pool=variant == 'pool')
+    got = from_nhwc(ops, out)
+    assert rel_err(got, ref) < (1e-5 if dtype == torch.float32 else TOL[dtype])
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_group_norm_many_pixels_and_wide(ops, dtype):
+    gen = g(41)
+    for (n, c, h) in ((2, 64, 64), (1, 1536, 8)):
+        x = q(torch.randn(n, c, h, h, generator=gen) + 1.0, dtype)
+        gamma, beta = torch.randn(c, generator=gen), torch.randn(c, generator=gen)
+        ref = onet.silu(onet.group_norm(x, gamma, beta, 1e-6))
+        out = ops.group_norm(to_nhwc(ops, x, dtype), min(32, c // 4), 1e-6, gamma.to(DEV), beta.to(DEV))
+        assert rel_err(from_nhwc(ops, out), ref) < (2e-5 if dtype == torch.float32 else TOL[dtype])
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_resample(ops, dtype):
+    x = q(torch.randn(2, 64, 8, 8, generator=g(5)), dtype)
+    xd = to_nhwc(ops, x, dtype)
+    assert rel_err(from_nhwc(ops, ops.resample2x(xd, up=False)), onet.resample_down(x)) < TOL[dtype]
+    assert torch.equal(from_nhwc(ops, ops.resample2x(xd, up=True)), onet.resample_up(x))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(2, 64, 2, 64), (1, 256, 3, 64), (2, 65, 2, 64), (1, 64, 1, 128), (1, 256, 1, 256), (1, 1024, 2, 64)])
+def test_attention(ops, dtype, shape):
+    n, t, heads, d = shape
+    gen = g(6)
+    c = heads * d
+    qkv = q(torch.randn(n, t, 3 * c, generator=gen), dtype)
+    qh = qkv[..., :c].reshape(n, t, heads, d).permute(0, 2, 3, 1).reshape(n * heads, d, t)
+    kh = qkv[..., c:2 * c].reshape(n, t, heads, d).permute(0, 2, 3, 1).reshape(n * heads, d, t)
+    vh = qkv[..., 2 * c:].reshape(n, t, heads, d).permute(0, 2, 3, 1).reshape(n * heads, d, t)
+    w = onet.attention_weights(qh, kh)                       # [nh, tq, tk]
+    a = torch.einsum('nqk,nck->ncq', w, vh)                  # [nh, d, t]
+    ref = a.reshape(n, heads, d, t).permute(0, 3, 1, 2).reshape(n, t, c)
+    out = ops.attention(qkv.to(DEV, dtype), heads, 1.0 / math.sqrt(d)).float().cpu()
+    assert rel_err(out, ref) < (3e-5 if dtype == torch.float32 else TOL[dtype])
+
+
+def test_linear_and_pos_embedding(ops):
+    gen = g(7)
+    x = torch.randn(5, 100, generator=gen)
+    w, b = torch.randn(37, 100, generator=gen), torch.randn(37, generator=gen)
+    got = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), act_in=True, act_out=True).cpu()
+    ref = onet.silu(F.linear(onet.silu(x), w, b))
+    assert rel_err(got, ref) < 1e-5
+    acc = ops.linear(x.to(DEV), w.to(DEV), None, out=got.to(DEV).clone(), accumulate=True).cpu()
+    assert rel_err(acc, ref + F.linear(x, w)) < 1e-5
+    v = torch.tensor([-1.3, 0.02, 1.09])
+    half = 32
+    freqs = (1 / 10000) ** (torch.arange(half, dtype=torch.float32) / half)
+    ref = onet.positional_embedding(v, 2 * half)
+    assert rel_err(ops.pos_embedding(v.to(DEV), freqs.to(DEV)).cpu(), ref) < 1e-6
+    sw = ref.reshape(3, 2, -1).flip(1).reshape(3, -1)
+    assert rel_err(ops.pos_embedding(v.to(DEV), freqs.to(DEV), swap=True).cpu(), sw) < 1e-6
+
+
+def test_precond_and_heun(ops):
+    gen = g(8)
+    x = torch.randn(4, 3, 8, 8, generator=gen, dtype=torch.float64) * 10
+    for sig in (torch.tensor([3.7], dtype=torch.float64), torch.tensor([80.0, 1.0, 0.3, 0.002], dtype=torch.float64)):
+        xin, coef = ops.edm_precond_in(x.to(DEV), sig.to(DEV), 0.5)
+        s = sig.float().reshape(-1, 1, 1, 1)
+        c_in = 1 / (0.25 + s ** 2).sqrt()
+        assert rel_err(xin.cpu(), c_in * x.float()) < 1e-6
+        Fx = torch.randn(4, 3, 8, 8, generator=gen)
+        D = ops.edm_precond_out(x.to(DEV), Fx.to(DEV), coef).cpu()
+        ref = 0.25 / (s ** 2 + 0.25) * x.float() + s * 0.5 / (s ** 2 + 0.25).sqrt() * Fx
+        assert rel_err(D, ref) < 1e-6
+        assert rel_err(coef[:, 3].cpu(), (s.flatten().log() / 4).expand(4)) < 1e-6
+    # Heun step against the oracle's step with a fixed analytic "denoiser"
+    class Net:
+        def round_sigma(self, s):
+            return torch.as_tensor(s)
+
+        def __call__(self, xx, sigma, labels=None):
+            return (xx.float() * 0.3 + 0.1)
+    ctx = osamp._Ctx(Net(), 18, 40, 0.05, 50, 1.003)
+    t = osamp.sigma_schedule(Net(), 18)
+    xc = torch.randn(1, 3, 8, 8, generator=gen, dtype=torch.float64) * 5
+    eps = torch.randn(6, 3, 8, 8, generator=gen, dtype=torch.float64)
+    for i in (0, 5, 17):
+        t_cur, t_next = t[i], t[i + 1]
+        ref_next, _ = ctx.heun_step(xc.repeat(6, 1, 1, 1), t_cur, t_next, i, eps, None)
+        gamma = min(40 / 18, math.sqrt(2) - 1) if 0.05 <= float(t_cur) <= 50 else 0
+        t_hat = float(t_cur) + gamma * float(t_cur)
+        coef = math.sqrt(t_hat ** 2 - float(t_cur) ** 2) * 1.003
+        x_hat = ops.heun_xhat(xc.to(DEV), eps.to(DEV), coef, 6)
+        D = (x_hat.float() * 0.3 + 0.1)
+        d_cur, x_next = ops.heun_euler(x_hat, D.contiguous(), t_hat, float(t_next))
+        if i < 17:
+            D2 = (x_next.float() * 0.3 + 0.1)
+            ops.heun_correct(x_hat, D2.contiguous(), d_cur, t_hat, float(t_next), x_next)
+        assert float((x_next.cpu() - ref_next).abs().max()) < 1e-12 * max(1.0, float(ref_next.abs().max()))
+    # repeat_interleave order and f32 noise
+    xb = torch.randn(2, 3, 4, 4, generator=gen, dtype=torch.float64)
+    e32 = torch.randn(6, 3, 4, 4, generator=gen)
+    got = ops.heun_xhat(xb.to(DEV), e32.to(DEV), 0.5, 6, interleave=True).cpu()
+    assert torch.allclose(got, xb.repeat_interleave(3, 0) + 0.5 * e32.double(), atol=1e-15)
+
+
+def test_quantize_brightness_softmax(ops):
+    gen = g(9)
+    x = torch.randn(4, 3, 16, 16, generator=gen, dtype=torch.float64) * 1.2
+    u = ops.quantize_u8(x.to(DEV))
+    assert torch.equal(u.cpu(), osamp.to_uint8(x))
+    assert torch.equal(ops.quantize_u8(x.float().to(DEV)).cpu(), osamp.to_uint8(x.float()))
+    b = ops.brightness(u).cpu()
+    assert torch.allclose(b, oscore.BrightnessOracle()(osamp.to_uint8(x), None, None), atol=2e-7)
+    assert torch.equal(ops.u8_to_unit_f32(u).cpu(), osamp.to_uint8(x).float() / 255.0)
+    logits = torch.randn(5, 1000, generator=gen) * 3
+    tgt = torch.tensor([0, 999, 5, 77, 500], dtype=torch.int32)
+    ref = torch.softmax(logits, 1)[torch.arange(5), tgt.long()]
+    assert torch.allclose(ops.softmax_gather(logits.to(DEV), tgt.to(DEV)).cpu(), ref, rtol=2e-6, atol=1e-9)
+
+
+def test_candidate_noise(ops):
+    gen = g(10)
+    B, N = 2, 5
+    pivot = torch.randn(B, 3, 8, 8, generator=gen, dtype=torch.float64)
+    gg = torch.randn(N * B, 3, 8, 8, generator=gen, dtype=torch.float64)
+    mode = torch.tensor([1, 0, 1, 1, 0], dtype=torch.int32)
+    scale = (torch.ones(N) * torch.tensor([0.1, 0.0, 0.731, 0.999, 0.5]) * (0.15 * np.sqrt(3 * 64 * 64))).float()
+    ref = []
+    for n in range(N):
+        u = gg[n * B:(n + 1) * B]
+        if mode[n] == 1:
+            u = u / torch.norm(u, p=2, dim=(1, 2, 3), keepdim=True)
+            ref.append(pivot + scale[n].reshape(1, 1, 1, 1) * u)
+        else:
+            ref.append(u)
+    ref = torch.cat(ref, 0)
+    got = ops.candidate_noise(pivot.to(DEV), gg.to(DEV), mode.to(DEV), scale.to(DEV)).cpu()
+    assert float((got - ref).abs().max()) < 1e-14
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_attnpool_tokens_and_take(ops, dtype):
+    gen = g(12)
+    n, c, r = 2, 64, 4
+    x = q(torch.randn(n, c, r, r, generator=gen), dtype)
+    pos = torch.randn(c, r * r + 1, generator=gen)
+    xf = x.reshape(n, c, -1)
+    ref = torch.cat([xf.mean(-1, keepdim=True), xf], -1) + pos[None]        # [n, c, t]
+    tok = ops.attnpool_tokens(to_nhwc(ops, x, dtype), pos.to(DEV))
+    assert rel_err(tok.float().cpu(), ref.permute(0, 2, 1)) < TOL[dtype]
+    assert torch.equal(ops.take_token(tok, 0).cpu(), tok[:, 0].float().cpu())
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+def test_ddim_candidates(ops, dtype):
+    gen = g(13)
+    x = q(torch.randn(1, 4, 8, 8, generator=gen), dtype)
+    e = q(torch.randn(1, 4, 8, 8, generator=gen), dtype)
+    z = q(torch.randn(3, 1, 4, 8, 8, generator=gen), dtype)
+    a_t, a_p = 0.3, 0.45
+    var = (1 - a_p) / (1 - a_t) * (1 - a_t / a_p)
+    sig = 1.0 * math.sqrt(var)
+    x0 = (x - math.sqrt(1 - a_t) * e) / math.sqrt(a_t)
+    ref = math.sqrt(a_p) * x0 + math.sqrt(1 - a_p - sig ** 2) * e + sig * z
+    prev, x0g = ops.ddim_candidates(x.to(DEV, dtype), e.to(DEV, dtype), z.to(DEV, dtype), a_t, a_p, sig)
+    assert rel_err(prev.float().cpu(), ref) < TOL[dtype] and rel_err(x0g.float().cpu(), x0) < TOL[dtype]
+
+
+def test_errors_are_loud(ops):
+    x = torch.zeros(1, 4, 4, 48, device=DEV)
+    w = torch.zeros(64, 3, 3, 48, device=DEV)
+    with pytest.raises(RuntimeError, match='channels'):
+        ops.conv2d(x, w)
+    with pytest.raises(RuntimeError, match='GPU tensor'):
+        ops.quantize_u8(torch.zeros(4, dtype=torch.float64))
