@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- candidate U-Net steps/sec of the noise-trajectory-search hot path on MI355X.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): EDM ImageNet-64 (ADM, 295.9 M
+parameters, random init + the documented weight rule), epsilon-greedy search, N = 64 candidates, ImageNet scorer
+(65.4 M-parameter classifier, random init), sigma step i = 5 of the 18-step schedule with S_churn = 40.
+One "step" = ONE search iteration over the candidate batch: build the 64 candidate noises (K14), one Heun step =
+two denoiser forwards over the 64 candidates (K1-K9), quantise (K10), score the 64 predicted images (K12), gather
+rewards, pick the survivor and rebuild the pivot.  That is 2*64 = 128 candidate U-Net evaluations ("candidate
+U-Net steps") per GPU per step.  Synthetic inputs (N(0,1) latents and noises) are resident in HBM before the timed
+region; the host-RNG + upload inclusive rate is reported separately in DESIGN.md.
+
+Multi-GPU (`--gpus N`, launched by torch.distributed.run): candidates are sharded across ranks, 64 per GPU (weak
+scaling, default) or 64 in total (`--scaling strong`); one RCCL all-gather of the rewards per step.
+
+Prints ONE JSON line on rank 0 (see the field list in the task contract), including `roofline` for the dominant
+kernel (the implicit-GEMM conv: algorithmic conv FLOPs / summed launch durations measured with HIP events on the
+launch stream) and `cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
+ADM_GFLOP_PER_EVAL = 219.33
+CLS_GFLOP_PER_IMG = 38.16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=6)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f32'])
+    ap.add_argument('--candidates', type=int, default=64, help='candidates per GPU (weak) or in total (strong)')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
+    ap.add_argument('--scorer', default='imagenet', choices=['imagenet', 'brightness'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, default=8, help='candidates in the CPU-baseline sample')
+    return ap.parse_args()
+
+
+def cpu_baseline(sample_n, seed=0):
+    """The oracle (CPU restatement of the reference, fp32 torch-CPU ops) on this box's host cores: one epsilon-greedy
+    iteration over `sample_n` candidates = 2*sample_n denoiser rows + sample_n classifier images."""
+    from diffusion_tts_amd import init as dinit
+    from diffusion_tts_amd.config import adm_imagenet64, ClassifierConfig
+    from oracle.edm_nets import NetCfg, EDMPrecondOracle
+    from oracle.classifier import ClsCfg
+    from oracle import sampler as osamp, scorers as oscore
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = adm_imagenet64()
+    sd, _ = dinit.refill_degenerate(dinit.edm_state_dict(cfg, seed), seed)
+    net = EDMPrecondOracle(NetCfg('adm', 64, 3, 1000, 192, [1, 2, 3, 4], 4, 3, [32, 16, 8]), sd)
+    csd, _ = dinit.refill_degenerate(dinit.classifier_state_dict(ClassifierConfig(), 1), 1)
+    scorer = oscore.ImageNetOracle(ClsCfg(), csd)
+    t_steps = osamp.sigma_schedule(net, 18)
+    ctx = osamp._Ctx(net, 18, 40, 0.05, 50, 1.003)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(1, 3, 64, 64, generator=g, dtype=torch.float64) * t_steps[5]
+    eps = torch.randn(sample_n, 3, 64, 64, generator=g, dtype=torch.float64)
+    lab = torch.eye(1000)[torch.tensor([7])].repeat(sample_n, 1)
+    t0 = time.perf_counter()
+    _, x0 = ctx.heun_step(x.repeat(sample_n, 1, 1, 1), t_steps[5], t_steps[6], 5, eps, lab)
+    sc = scorer(osamp.to_uint8(x0), lab, torch.zeros(sample_n))
+    int(sc.argmax())
+    dt = time.perf_counter() - t0
+    return {'value': round(2 * sample_n / dt, 3), 'unit': 'candidate U-Net steps/sec', 'cores': torch.get_num_threads(),
+            'kind': 'port', 'seconds': round(dt, 2),
+            'sample': f'1 eps-greedy iteration over {sample_n} candidates of the same workload: {2 * sample_n} ADM-64 '
+                      f'denoiser rows + {sample_n} classifier images, fp32 torch-CPU oracle'}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    if a.gpus != world and rank == 0 and world > 1:
+        print(f'warning: --gpus {a.gpus} but WORLD_SIZE {world}', file=sys.stderr)
+    dev = torch.device('cuda', local if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from diffusion_tts_amd import init as dinit, ops
+    from diffusion_tts_amd.config import adm_imagenet64
+    from diffusion_tts_amd.networks import EDMPrecond
+    from diffusion_tts_amd.parallel import CandidateShards
+    from diffusion_tts_amd.sampler import _Loop
+    from diffusion_tts_amd.scorers import ImageNetScorer, BrightnessScorer
+
+    dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[a.dtype]
+    cfg = adm_imagenet64()
+    sd, _ = dinit.refill_degenerate(dinit.edm_state_dict(cfg, 0), 0)
+    net = EDMPrecond(cfg, sd, device=dev, dtype=dtype)
+    del sd
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        scorer = ImageNetScorer(device=dev, compute_dtype=dtype, seed=1) if a.scorer == 'imagenet' else BrightnessScorer()
+    shards = CandidateShards()
+    n_total = a.candidates * world if a.scaling == 'weak' else a.candidates
+    lo, hi = shards.span(n_total)
+    nl = hi - lo
+
+    # ---- synthetic state, resident in HBM before timing
+    g = torch.Generator().manual_seed(1234)                       # same stream on every rank
+    L = _Loop(net, dev, 18, 40, 0.05, 50, 1.003, None, shards)
+    step_indices = torch.arange(18, dtype=torch.float64)
+    t_steps = (80 ** (1 / 7) + step_indices / 17 * (0.002 ** (1 / 7) - 80 ** (1 / 7))) ** 7
+    t_steps = torch.cat([t_steps, torch.zeros(1, dtype=torch.float64)])
+    i_step = 5
+    x_cur = (torch.randn(1, 3, 64, 64, generator=g, dtype=torch.float64) * t_steps[i_step]).to(dev)
+    pivot = torch.randn(1, 3, 64, 64, generator=g, dtype=torch.float64).to(dev)
+    labels = torch.eye(1000)[torch.tensor([7])].to(dev)
+    lab_l = labels.repeat(nl, 1).contiguous()
+    total_steps = a.warmup + a.steps
+    noise, modes, scales = [], [], []
+    lam = 0.15 * np.sqrt(3 * 64 * 64)
+    for s in range(min(total_steps, 4)):                          # 4 distinct noise sets, cycled
+        gfull = torch.randn(n_total, 3, 64, 64, generator=g, dtype=torch.float64)
+        noise.append(gfull[lo:hi].to(dev).contiguous())
+        m = (torch.rand(n_total, generator=g) < 0.6).to(torch.int32)
+        sc = (torch.rand(n_total, generator=g) * lam).float()
+        modes.append((m, m[lo:hi].to(dev).contiguous()))
+        scales.append((sc, sc[lo:hi].to(dev).contiguous()))
+    state = {'pivot': pivot}
+
+    def one_step(s):
+        q = s % len(noise)
+        cand = ops.candidate_noise(state['pivot'], noise[q], modes[q][1], scales[q][1])
+        _, x0 = L.step(x_cur, t_steps[i_step], t_steps[i_step + 1], i_step, cand, lab_l, nb=nl)
+        loc = L.score(scorer, x0, lab_l).to(dev, torch.float32)
+        scores = shards.gather_rewards(loc, n_total, 1).cpu()
+        best = int(scores.argmax())
+        if lo <= best < hi:                                       # survivor rebuilt locally; replicated via host noise in the real loop
+            j = best - lo
+            state['pivot'] = ops.candidate_noise(state['pivot'], noise[q][j:j + 1].contiguous(), modes[q][1][j:j + 1].contiguous(),
+                                                 scales[q][1][j:j + 1].contiguous())
+        return best
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for s in range(a.warmup):
+        one_step(s)
+    evals0 = net.evals
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(a.steps):
+        one_step(a.warmup + s)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    rows_local = net.evals - evals0
+    rows_total = 2 * n_total * a.steps
+    value = rows_total / dt
+
+    # ---- per-kernel timing of the dominant kernel (implicit-GEMM conv) with HIP events on the launch stream
+    roof = None
+    if not a.no_kernel_timing and rank == 0:
+        rec = []
+        orig = ops.conv2d
+
+        def timed_conv(x1, w, bias=None, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig(x1, w, bias, **kw)
+            e1.record()
+            n_, ho, wo, co = out.shape
+            rec.append((2.0 * n_ * ho * wo * co * w.shape[1] * w.shape[2] * w.shape[3], e0, e1))
+            return out
+        ops.conv2d = timed_conv
+        try:
+            for s in range(min(2, a.steps)):
+                one_step(a.warmup + s)
+            torch.cuda.synchronize(dev)
+        finally:
+            ops.conv2d = orig
+        fl = sum(r[0] for r in rec)
+        ms = sum(r[1].elapsed_time(r[2]) for r in rec)
+        ach = fl / (ms * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[a.dtype]
+        roof = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                'traffic': None, 'kernel': 'conv_igemm_kernel', 'launches': len(rec),
+                'avg_launch_us': round(ms * 1e3 / len(rec), 2), 'avg_launch_gflop': round(fl / len(rec) / 1e9, 3),
+                'conv_ms_per_step': round(ms / min(2, a.steps), 2),
+                'whole_step_frac': round((value / world) * ADM_GFLOP_PER_EVAL * 1e9 / (peak * 1e12), 4)}
+    if world > 1:
+        dist.barrier()
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.cpu_sample)
+
+    if rank == 0:
+        out = {
+            'metric': 'candidate U-Net steps/sec, EDM ImageNet-64 eps-greedy N=64', 'value': round(value, 2),
+            'unit': 'candidate U-Net steps/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': a.scaling,
+            'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic (N(0,1) latents/noises, random-init weights + weight rule)',
+            'config': {'workload': 'EDM ImageNet-64 (ADM 295.9M) eps-greedy search iteration, imagenet scorer, sigma step 5/18',
+                       'candidates_total': n_total, 'candidates_per_gpu': nl, 'rows_per_step_total': 2 * n_total,
+                       'scorer': a.scorer, 'parallelism': f'candidates sharded x{world}, 1 all-gather of rewards per step'},
+            'roofline': roof, 'cpu_baseline': cpu,
+            'scorer_images_per_sec': round(n_total * a.steps / dt, 2), 'rows_local': rows_local,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -5,6 +5,9 @@ There is no CPU fallback: if the HIP library has not been built, or a kernel cal
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- must come first: torch ships its own libamdhip64; loading ours before it would give the
+#                              process two HIP runtimes (kernels would then launch on a runtime with no device context)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdts_hip.so')
 

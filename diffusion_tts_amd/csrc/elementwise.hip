@@ -137,8 +137,10 @@ __global__ void heun_correct_kernel(const double* __restrict__ x_hat, const floa
 template <typename E>
 __global__ void quantize_kernel(const E* __restrict__ x, uint8_t* __restrict__ out, long long count) {
   GSL(i, count) {
-    E v = x[i] * (E)127.5 + (E)128;
-    v = v < (E)0 ? (E)0 : (v > (E)255 ? (E)255 : v);
+    // the reference converts the f32 denoiser output to f64 first (edm/main.py:87,92 .to(float64)), so the
+    // affine map and the clip run in f64 whatever the storage type
+    double v = (double)x[i] * 127.5 + 128.0;
+    v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
     out[i] = (uint8_t)v;                                   // truncation, as Tensor.to(torch.uint8)
   }
 }
@@ -185,9 +187,10 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
     acc = wave_sum(acc);
     if (lane == 0) {
       float v = acc + (bias ? bias[col] : 0.f);
-      if (act_out) v = silu_f(v);
       float* o = y + (size_t)row * ldy + col;
-      *o = accumulate ? (*o + v) : v;
+      if (accumulate) v += *o;
+      if (act_out) v = silu_f(v);
+      *o = v;
     }
   }
 }

@@ -204,7 +204,7 @@ extern "C" int dts_gn_coef(const void* x1, int c1, const void* x2, int c2, int d
   DTS_CHECK_ARG(c2 == 0 || x2, "dts_gn_coef: c2 without x2");
   const int epv = dtype == DTS_F32 ? 4 : 8;
   DTS_CHECK_ARG(c1 % epv == 0 && c2 % epv == 0, "dts_gn_coef: channels (%d,%d) unsupported", c1, c2);
-  DTS_CHECK_ARG(scale_shift == nullptr || ld_ss >= 2 * C, "dts_gn_coef: ld_ss");
+  DTS_CHECK_ARG(scale_shift == nullptr || ld_ss >= 2 * C, "dts_gn_coef: ld_ss=%d < 2*C=%d", ld_ss, 2 * C);
   const int splits = gn_splits(hw);
   hipStream_t st = to_stream(s);
   DTS_DISPATCH_DTYPE(dtype, {

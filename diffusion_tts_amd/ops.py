@@ -36,6 +36,17 @@ def _ptr(t, name='tensor', dtype=None):
     return t.data_ptr()
 
 
+def _rows(t, name, dtype):
+    """(pointer, leading dimension) of a 2-D row-major view whose rows may be strided (a column slice)."""
+    if t is None:
+        return None, 0
+    if not t.is_cuda:
+        raise RuntimeError(f'{name} must be a GPU tensor (the HIP path has no CPU fallback)')
+    if t.dim() != 2 or t.stride(1) != 1 or t.dtype != dtype:
+        raise ValueError(f'{name}: expected a 2-D {dtype} view with unit inner stride')
+    return t.data_ptr(), t.stride(0)
+
+
 def _call(name, *args):
     lib = L.load()
     L.check(getattr(lib, name)(*args, _stream()), name)
@@ -83,8 +94,7 @@ def conv2d(x1, w, bias=None, *, x2=None, bias_nc=None, residual=None, up=False, 
     a.x2, a.c2 = _ptr(x2, 'x2', x1.dtype), c2
     a.w = _ptr(w, 'w', x1.dtype)
     a.bias = _ptr(bias, 'bias', torch.float32)
-    a.bias_nc = _ptr(bias_nc, 'bias_nc', x1.dtype)
-    a.ld_bias_nc = 0 if bias_nc is None else bias_nc.shape[-1]
+    a.bias_nc, a.ld_bias_nc = _rows(bias_nc, 'bias_nc', x1.dtype)
     a.residual = _ptr(residual, 'residual', x1.dtype)
     if residual is not None and tuple(residual.shape) != (n, ho, wo, cout):
         raise ValueError(f'conv2d: residual shape {tuple(residual.shape)} != {(n, ho, wo, cout)}')
@@ -122,10 +132,9 @@ def gn_coef(x1, groups, eps, gamma, beta, *, x2=None, scale_shift=None):
     lib = L.load()
     ws = torch.empty((lib.dts_gn_ws_floats(n, groups),), dtype=torch.float32, device=x1.device)
     coef = torch.empty((n, C_, 2), dtype=torch.float32, device=x1.device)
+    ss_ptr, ss_ld = _rows(scale_shift, 'scale_shift', x1.dtype)
     _call('dts_gn_coef', _ptr(x1, 'x1'), c1, _ptr(x2, 'x2', x1.dtype), c2, dt_code(x1.dtype), n, h * w, groups, float(eps),
-          _ptr(gamma, 'gamma', torch.float32), _ptr(beta, 'beta', torch.float32),
-          _ptr(scale_shift, 'scale_shift', x1.dtype), 0 if scale_shift is None else scale_shift.shape[-1],
-          _ptr(coef), _ptr(ws))
+          _ptr(gamma, 'gamma', torch.float32), _ptr(beta, 'beta', torch.float32), ss_ptr, ss_ld, _ptr(coef), _ptr(ws))
     return coef
 
 

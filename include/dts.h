@@ -91,7 +91,7 @@ int dts_resample2x(const void* x, void* out, int dtype, int n, int h, int w, int
 int dts_attention(const void* qkv, void* out, int dtype, int n, int t, int heads, int d, float scale, dts_stream s);
 
 /* ---- K7/K8: embedding MLP pieces and EDM preconditioning (networks.py:200-206,437-447,654-668) ---- */
-/* y[m][n] = act_out( act_in(x[m][:]) . w[n][:] + bias[n] ) (+ y if accumulate); all f32; act: 0 none, 1 SiLU */
+/* y[m][n] = act_out( act_in(x[m][:]) . w[n][:] + bias[n] (+ y[m][n] if accumulate) ); all f32; act: 0 none, 1 SiLU */
 int dts_linear(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy,
                int m, int k, int n, int act_in, int act_out, int accumulate, dts_stream s);
 /* out[n][0:half] = cos(v[n]*freqs), out[n][half:2half] = sin(..) (swap=1: sin first, networks.py:323) */
@@ -118,7 +118,7 @@ int dts_heun_correct(const double* x_hat, const float* D2, const double* d_cur, 
                      double* x_next, int64_t count, dts_stream s);
 
 /* ---- K10/K11: scorer pre-processing and brightness reward (edm/main.py:126; scorers.py:38-52) ----- */
-/* u8 = trunc(clip(x*127.5+128, 0, 255)); x is f64 (is_f32=0) or f32 */
+/* u8 = trunc(clip(f64(x)*127.5+128, 0, 255)); x is f64 (is_f32=0) or f32; the arithmetic is f64 either way */
 int dts_quantize_u8(const void* x, int is_f32, uint8_t* out, int64_t count, dts_stream s);
 /* rewards[n] = clamp(mean_hw(0.2126 R + 0.7152 G + 0.0722 B)/1, 0, 1) on u8/255 images NCHW [n][3][h][w] */
 int dts_brightness(const uint8_t* img, float* rewards, int n, int hw, dts_stream s);

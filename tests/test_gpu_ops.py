@@ -258,7 +258,7 @@ def test_quantize_brightness_softmax(ops):
     x = torch.randn(4, 3, 16, 16, generator=gen, dtype=torch.float64) * 1.2
     u = ops.quantize_u8(x.to(DEV))
     assert torch.equal(u.cpu(), osamp.to_uint8(x))
-    assert torch.equal(ops.quantize_u8(x.float().to(DEV)).cpu(), osamp.to_uint8(x.float()))
+    assert torch.equal(ops.quantize_u8(x.float().to(DEV)).cpu(), osamp.to_uint8(x.float().double()))
     b = ops.brightness(u).cpu()
     assert torch.allclose(b, oscore.BrightnessOracle()(osamp.to_uint8(x), None, None), atol=2e-7)
     assert torch.equal(ops.u8_to_unit_f32(u).cpu(), osamp.to_uint8(x).float() / 255.0)
