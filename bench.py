@@ -35,6 +35,14 @@ ADM_GFLOP_PER_EVAL = 219.33                                       # BASELINE.md 
 CLS_GFLOP_PER_IMG = 38.16
 
 
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    if int(os.environ.get('RANK', '0')) == 0:
+        print(f'[bench +{time.perf_counter() - _T0:7.1f}s] {msg}', file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -58,7 +66,9 @@ def cpu_baseline(sample_n, seed=0):
     from oracle.edm_nets import NetCfg, EDMPrecondOracle
     from oracle.classifier import ClsCfg
     from oracle import sampler as osamp, scorers as oscore
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's share of the host (16 cores); asking torch for every core the machine has
+    # oversubscribes the cgroup quota and runs ~100x slower
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
     torch.set_num_threads(cores)
     cfg = adm_imagenet64()
     sd, _ = dinit.refill_degenerate(dinit.edm_state_dict(cfg, seed), seed)
@@ -106,8 +116,10 @@ def main():
     dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[a.dtype]
     cfg = adm_imagenet64()
     sd, _ = dinit.refill_degenerate(dinit.edm_state_dict(cfg, 0), 0)
+    log('weights initialised on host')
     net = EDMPrecond(cfg, sd, device=dev, dtype=dtype)
     del sd
+    log('denoiser packed on device')
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
@@ -158,8 +170,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    log(f'state resident; {nl} candidates on this rank; warmup')
     for s in range(a.warmup):
         one_step(s)
+        torch.cuda.synchronize(dev)
+        log(f'warmup step {s} done')
     evals0 = net.evals
     barrier()
     t0 = time.perf_counter()
@@ -171,6 +186,7 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
+    log(f'timed region: {dt:.3f}s for {a.steps} steps')
     rows_local = net.evals - evals0
     rows_total = 2 * n_total * a.steps
     value = rows_total / dt
@@ -183,6 +199,9 @@ def main():
 
         def timed_conv(x1, w, bias=None, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            # keep the GPU busy while the host enqueues (e0, kernel, e1): otherwise the pair brackets the host's
+            # launch latency as well and the short kernels read 20-40 % long (checked against rocprofv3)
+            torch.cuda._sleep(200_000)
             e0.record()
             out = orig(x1, w, bias, **kw)
             e1.record()
@@ -210,7 +229,9 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        log('kernel timing done; CPU baseline (oracle) running')
         cpu = cpu_baseline(a.cpu_sample)
+        log('CPU baseline done')
 
     if rank == 0:
         out = {

@@ -13,8 +13,11 @@
 // Tile: 256 threads = 4 waves; block tile (64*WM couts) x (64*WN pixels), WM*WN = 4; wave tile 64x64
 // = 4x4 MFMA 16x16 tiles; K step = 128 bytes per row (64 bf16/f16, 32 f32).  LDS rows are 128 B with the
 // 16-byte chunk index XOR-swizzled by (row & 7): conflict-free ds_read_b128 fragment reads.
-// Global->register->LDS staging, double-buffered, the next tile's loads issued before the MFMAs of the
-// current one.  f32 mode uses v_mfma_f32_16x16x4_f32 (exact f32 FMA chain) = the parity path.
+// Staging is LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction straight into LDS, no VGPR round trip and
+// no ds_write -- the register-staged version was LDS-write-bound); the LDS image is lane-linear, so the XOR swizzle is
+// applied to the per-lane SOURCE chunk and again on the fragment read.  Out-of-image rows read a 16-byte zero word.
+// Double-buffered: tile k+1 is in flight while tile k feeds the MFMAs.
+// f32 mode uses v_mfma_f32_16x16x4_f32 (exact f32 FMA chain) = the parity path.
 #include "dts_common.h"
 
 namespace {
@@ -58,6 +61,56 @@ template <> struct Mma<float> {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), acc, 0, 0, 0);
   }
 };
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+  using type = float4;
+  static __device__ __forceinline__ void load(const float* p, float* f) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float* f) {
+    *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+  }
+};
+template <> struct Vec4<bf16_t> {
+  using type = uint2;
+  static __device__ __forceinline__ void load(const bf16_t* p, float* f) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    f[0] = bf16_bits_to_f32(v.x & 0xffffu); f[1] = bf16_bits_to_f32(v.x >> 16);
+    f[2] = bf16_bits_to_f32(v.y & 0xffffu); f[3] = bf16_bits_to_f32(v.y >> 16);
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float* f) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(f32_to_bf16_bits(f[0]) | (f32_to_bf16_bits(f[1]) << 16),
+                                              f32_to_bf16_bits(f[2]) | (f32_to_bf16_bits(f[3]) << 16));
+  }
+};
+template <> struct Vec4<f16_t> {
+  using type = uint2;
+  static __device__ __forceinline__ void load(const f16_t* p, float* f) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    f[0] = f16_bits_to_f32(v.x & 0xffffu); f[1] = f16_bits_to_f32(v.x >> 16);
+    f[2] = f16_bits_to_f32(v.y & 0xffffu); f[3] = f16_bits_to_f32(v.y >> 16);
+  }
+  static __device__ __forceinline__ void store(f16_t* p, const float* f) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(f32_to_f16_bits(f[0]) | (f32_to_f16_bits(f[1]) << 16),
+                                              f32_to_f16_bits(f[2]) | (f32_to_f16_bits(f[3]) << 16));
+  }
+};
+
+__device__ uint4 g_zero16[1];      // source of padded (out-of-image) rows
+
+// LDS-DMA through inline asm: hipcc does not count an asm memory op in its s_waitcnt bookkeeping, so it does not
+// drain the in-flight tile in front of the (non-aliasing) ds_reads of the other buffer, as it does for the builtin.
+// Completion is awaited explicitly (s_waitcnt vmcnt(0) before the barrier that publishes the tile).
+// lds_off must be wave-uniform (LDS byte address of this wave-instruction's 1 KiB destination).
+__device__ __forceinline__ void glds16(const char* g, uint32_t lds_off) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(g), "s"(lds_off)
+               : "memory");
+}
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
@@ -110,10 +163,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
   const int K = p_taps * p_cin;
   const int steps_per_tap = p_cin / BKE;
   const int nk = p_taps * steps_per_tap;
-  const char* wbase = p_w + ((size_t)(cm0 + r0) * K) * ES + chunk * 16;
 
   int src_pix[RB];                                     // source pixel index (or -1) for the current tap
-  uint4 rb[RB]; uint4 ra0, ra1, ra2, ra3;
+  const int schunk = (chunk ^ (r0 & 7)) * 16;          // source chunk of this lane's (linear) LDS slot
+  const char* wsrc = p_w + ((size_t)(cm0 + r0) * K) * ES + schunk;
+  const char* zsrc = reinterpret_cast<const char*>(g_zero16);
+  // LDS byte address of this wave's 8 rows inside each 32-row slab (wave-uniform by construction)
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const uint32_t wave_rows = __builtin_amdgcn_readfirstlane(lds_base + (tid >> 6) * 8 * 128);
 
 #define SET_TAP(tap_)                                                                                         \
   {                                                                                                           \
@@ -125,28 +182,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
       src_pix[j] = ok ? pix_n[j] + hs * p_win + ws : -1;                                                      \
     }                                                                                                         \
   }
-#define LOAD_TILE(ks_, ci0_)                                                                                  \
+#define ISSUE_TILE(buf_, ks_, ci0_)                                                                           \
   {                                                                                                           \
-    const char* wp = wbase + (size_t)(ks_) * BKE * ES;                                                        \
-    ra0 = *reinterpret_cast<const uint4*>(wp); ra1 = *reinterpret_cast<const uint4*>(wp + (size_t)32 * K * ES); \
-    if (RA > 2) { ra2 = *reinterpret_cast<const uint4*>(wp + (size_t)64 * K * ES); ra3 = *reinterpret_cast<const uint4*>(wp + (size_t)96 * K * ES); } \
+    const uint32_t sa_ = wave_rows + (buf_) * (A_BYTES + B_BYTES);                                            \
+    const uint32_t sb_ = sa_ + A_BYTES;                                                                       \
+    const char* wp = wsrc + (size_t)(ks_) * BKE * ES;                                                         \
+    _Pragma("unroll") for (int j = 0; j < RA; ++j) glds16(wp + (size_t)(32 * j) * K * ES, sa_ + j * 32 * 128); \
     const char* xb; int cs, cofs;                                                                             \
     if ((ci0_) < p_c1) { xb = p_x1; cs = p_c1; cofs = (ci0_); } else { xb = p_x2; cs = p_c2; cofs = (ci0_) - p_c1; } \
     _Pragma("unroll") for (int j = 0; j < RB; ++j) {                                                          \
-      uint4 v = make_uint4(0, 0, 0, 0);                                                                       \
-      if (src_pix[j] >= 0)                                                                                    \
-        v = *reinterpret_cast<const uint4*>(xb + ((size_t)src_pix[j] * cs + cofs) * ES + chunk * 16);         \
-      rb[j] = v;                                                                                              \
+      const char* src = src_pix[j] >= 0 ? xb + ((size_t)src_pix[j] * cs + cofs) * ES + schunk : zsrc;         \
+      glds16(src, sb_ + j * 32 * 128);                                                                        \
     }                                                                                                         \
-  }
-#define STORE_TILE(buf_)                                                                                      \
-  {                                                                                                           \
-    char* sa_ = smem + (buf_) * (A_BYTES + B_BYTES);                                                          \
-    char* sb_ = sa_ + A_BYTES;                                                                                \
-    *reinterpret_cast<uint4*>(sa_ + swz(r0, chunk)) = ra0; *reinterpret_cast<uint4*>(sa_ + swz(r0 + 32, chunk)) = ra1; \
-    if (RA > 2) { *reinterpret_cast<uint4*>(sa_ + swz(r0 + 64, chunk)) = ra2; *reinterpret_cast<uint4*>(sa_ + swz(r0 + 96, chunk)) = ra3; } \
-    _Pragma("unroll") for (int j = 0; j < RB; ++j)                                                            \
-        *reinterpret_cast<uint4*>(sb_ + swz(r0 + 32 * j, chunk)) = rb[j];                                     \
   }
 
   f32x4_t acc[4][4];
@@ -157,18 +204,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
 
   int tap = 0, ci0 = 0;
   SET_TAP(0);
-  LOAD_TILE(0, 0);
-  STORE_TILE(0);
+  ISSUE_TILE(0, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const int lrow = lane & 15, lq = lane >> 4;
   for (int ks = 0; ks < nk; ++ks) {
     const int buf = ks & 1;
-    const bool more = ks + 1 < nk;
-    if (more) {
+    if (ks + 1 < nk) {
       ci0 += BKE;
       if (ci0 == p_cin) { ci0 = 0; ++tap; SET_TAP(tap); }
-      LOAD_TILE(ks + 1, ci0);
+      ISSUE_TILE(buf ^ 1, ks + 1, ci0);            // buf^1 was last read in iteration ks-1 (barrier passed)
     }
     const char* sa = smem + buf * (A_BYTES + B_BYTES) + (wm * 64) * 128;
     const char* sb = smem + buf * (A_BYTES + B_BYTES) + A_BYTES + (wn * 64) * 128;
@@ -184,15 +230,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
     }
-    if (more) STORE_TILE(buf ^ 1);
+    // tile ks+1 has landed (LDS-DMA is tracked by vmcnt) and this wave's LDS reads of tile ks have returned
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds couts co..co+3 of pixel pp for each (mt, nt)
+  // ---- epilogue: lane holds couts co..co+3 of pixel pp for each (mt, nt): one 4-element vector load/store
   const T* res = reinterpret_cast<const T*>(kp.residual);
   const T* bnc = reinterpret_cast<const T*>(kp.bias_nc);
   T* out = reinterpret_cast<T*>(kp.out);
   const int hw = p_hout * p_wout;
+  using V4 = typename Vec4<T>::type;
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
     const int pp = pn0 + wn * 64 + nt * 16 + lrow;
@@ -203,16 +251,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
       const int co = cm0 + wm * 64 + mt * 16 + lq * 4;
       float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float t = acc[mt][nt][r];
-        if (kp.bias) t += kp.bias[co + r];
-        if (bnc) t += ld1<T>(bnc + (size_t)n * kp.ld_bias_nc + co + r);
-        if (res) t += ld1<T>(res + (size_t)pp * p_cout + co + r);
-        v[r] = t * kp.out_scale;
+      for (int r = 0; r < 4; ++r) v[r] = acc[mt][nt][r];
+      if (kp.bias) {
+        const float4 bv = *reinterpret_cast<const float4*>(kp.bias + co);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
       }
-      T* o = out + (size_t)pp * p_cout + co;
+      if (bnc) {
+        float f[4];
+        Vec4<T>::load(bnc + (size_t)n * kp.ld_bias_nc + co, f);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) st1<T>(o + r, v[r]);
+        for (int r = 0; r < 4; ++r) v[r] += f[r];
+      }
+      if (res) {
+        float f[4];
+        Vec4<T>::load(res + (size_t)pp * p_cout + co, f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += f[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= kp.out_scale;
+      Vec4<T>::store(out + (size_t)pp * p_cout + co, v);
     }
   }
 }
