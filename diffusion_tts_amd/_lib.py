@@ -20,7 +20,8 @@ class ConvArgs(C.Structure):
     _fields_ = [('x1', _p), ('c1', C.c_int32), ('x2', _p), ('c2', C.c_int32), ('w', _p), ('bias', _p),
                 ('bias_nc', _p), ('ld_bias_nc', C.c_int32), ('residual', _p), ('out', _p),
                 ('n', C.c_int32), ('hin', C.c_int32), ('win', C.c_int32), ('cout', C.c_int32),
-                ('ksize', C.c_int32), ('up', C.c_int32), ('out_scale', C.c_float), ('dtype', C.c_int32)]
+                ('ksize', C.c_int32), ('up', C.c_int32), ('out_scale', C.c_float), ('dtype', C.c_int32),
+                ('workspace', _p), ('workspace_bytes', C.c_int64)]
 
 
 # name -> argtypes (every function returns int status except the three noted below)

@@ -10,9 +10,11 @@
 //   B operand = activation rows (row = pixel, K contiguous; zero rows outside the image)
 // so a lane's accumulator holds 4 consecutive couts of one pixel -> vector stores into NHWC.
 //
-// Tile: 256 threads = 4 waves; block tile (64*WM couts) x (64*WN pixels), WM*WN = 4; wave tile 64x64
-// = 4x4 MFMA 16x16 tiles; K step = 128 bytes per row (64 bf16/f16, 32 f32).  LDS rows are 128 B with the
-// 16-byte chunk index XOR-swizzled by (row & 7): conflict-free ds_read_b128 fragment reads.
+// Tile: 256 threads = 4 waves (WM x WN); wave tile (16*MT couts) x (16*NT pixels) of MFMA 16x16 tiles; block tile
+// 64x256, 128x128 or 192x128 (couts x pixels) chosen from cout's divisibility; K step = 128 bytes per row (64 bf16/f16,
+// 32 f32).  LDS rows are 128 B with the 16-byte chunk index XOR-swizzled by (row & 7): conflict-free ds_read_b128
+// fragment reads.  Layers with few pixels (8x8, 16x16 levels; sharded candidate batches) use split-K over grid.y with
+// f32 partial slabs and a fixed-order reduce kernel (deterministic: no float atomics), so the grid still fills 256 CUs.
 // Staging is LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction straight into LDS, no VGPR round trip and
 // no ds_write -- the register-staged version was LDS-write-bound); the LDS image is lane-linear, so the XOR swizzle is
 // applied to the per-lane SOURCE chunk and again on the fragment read.  Out-of-image rows read a 16-byte zero word.
@@ -37,6 +39,9 @@ struct ConvP {
   int P;           // n*hout*wout
   int n_ct;        // cout tiles
   int n_pt;        // pixel tiles
+  int splits;      // split-K factor (grid.y); > 1 => f32 partial slabs + dts reduce kernel
+  int ks_per_split;
+  float* partial;  // [splits][P][cout] f32 when splits > 1
   float out_scale;
 };
 
@@ -114,18 +119,20 @@ __device__ __forceinline__ void glds16(const char* g, uint32_t lds_off) {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
-template <typename T, int WM, int WN>
+template <typename T, int MT, int NT, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
   const char* const p_x1 = kp.x1; const char* const p_x2 = kp.x2; const char* const p_w = kp.w;
   const int p_c1 = kp.c1, p_c2 = kp.c2, p_cin = kp.cin, p_hin = kp.hin, p_win = kp.win, p_hout = kp.hout, p_wout = kp.wout;
   const int p_taps = kp.taps, p_up = kp.up, p_P = kp.P, p_cout = kp.cout, p_n_ct = kp.n_ct, p_n_pt = kp.n_pt;
-  constexpr int BM = 64 * WM;              // couts per block
-  constexpr int BN = 64 * WN;              // pixels per block
+  static_assert(WM * WN == 4, "4 waves per block");
+  constexpr int BM = 16 * MT * WM;         // couts per block
+  constexpr int BN = 16 * NT * WN;         // pixels per block
   constexpr int EPV = ET<T>::EPV;
   constexpr int BKE = 8 * EPV;             // K elements per step (128 bytes)
   constexpr int ES = 16 / EPV;             // element size
-  constexpr int RA = BM / 32;              // A rows per thread
-  constexpr int RB = BN / 32;              // B rows per thread
+  constexpr int RA = BM / 32;              // A wave-instructions (8 rows each) per wave
+  constexpr int RB = BN / 32;              // B wave-instructions per wave
+  static_assert(BM % 32 == 0 && BN % 32 == 0, "tile rows must split over 4 waves x 8 rows");
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -162,7 +169,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
   }
   const int K = p_taps * p_cin;
   const int steps_per_tap = p_cin / BKE;
-  const int nk = p_taps * steps_per_tap;
+  const int nk_all = p_taps * steps_per_tap;
+  const int ks_begin = blockIdx.y * kp.ks_per_split;
+  const int ks_end = min(nk_all, ks_begin + kp.ks_per_split);
 
   int src_pix[RB];                                     // source pixel index (or -1) for the current tap
   const int schunk = (chunk ^ (r0 & 7)) * 16;          // source chunk of this lane's (linear) LDS slot
@@ -196,39 +205,39 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
     }                                                                                                         \
   }
 
-  f32x4_t acc[4][4];
+  f32x4_t acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  int tap = 0, ci0 = 0;
-  SET_TAP(0);
-  ISSUE_TILE(0, 0, 0);
+  int tap = ks_begin / steps_per_tap, ci0 = (ks_begin - tap * steps_per_tap) * BKE;
+  SET_TAP(tap);
+  ISSUE_TILE(0, ks_begin, ci0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const int lrow = lane & 15, lq = lane >> 4;
-  for (int ks = 0; ks < nk; ++ks) {
-    const int buf = ks & 1;
-    if (ks + 1 < nk) {
+  for (int ks = ks_begin; ks < ks_end; ++ks) {
+    const int buf = (ks - ks_begin) & 1;
+    if (ks + 1 < ks_end) {
       ci0 += BKE;
       if (ci0 == p_cin) { ci0 = 0; ++tap; SET_TAP(tap); }
       ISSUE_TILE(buf ^ 1, ks + 1, ci0);            // buf^1 was last read in iteration ks-1 (barrier passed)
     }
-    const char* sa = smem + buf * (A_BYTES + B_BYTES) + (wm * 64) * 128;
-    const char* sb = smem + buf * (A_BYTES + B_BYTES) + A_BYTES + (wn * 64) * 128;
+    const char* sa = smem + buf * (A_BYTES + B_BYTES) + (wm * 16 * MT) * 128;
+    const char* sb = smem + buf * (A_BYTES + B_BYTES) + A_BYTES + (wn * 16 * NT) * 128;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      uint4 fa[4], fb[4];
+      uint4 fa[MT], fb[NT];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq + 4 * s));
+      for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq + 4 * s));
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const uint4*>(sb + swz(i * 16 + lrow, lq + 4 * s));
+      for (int i = 0; i < NT; ++i) fb[i] = *reinterpret_cast<const uint4*>(sb + swz(i * 16 + lrow, lq + 4 * s));
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
+        for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
     }
     // tile ks+1 has landed (LDS-DMA is tracked by vmcnt) and this wave's LDS reads of tile ks have returned
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -236,19 +245,33 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
   }
 
   // ---- epilogue: lane holds couts co..co+3 of pixel pp for each (mt, nt): one 4-element vector load/store
+  if (kp.splits > 1) {
+    float* part = kp.partial + (size_t)blockIdx.y * p_P * p_cout;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int pp = pn0 + wn * 16 * NT + nt * 16 + lrow;
+      if (pp >= p_P) continue;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int co = cm0 + wm * 16 * MT + mt * 16 + lq * 4;
+        *reinterpret_cast<float4*>(part + (size_t)pp * p_cout + co) =
+            make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+      }
+    }
+    return;
+  }
   const T* res = reinterpret_cast<const T*>(kp.residual);
   const T* bnc = reinterpret_cast<const T*>(kp.bias_nc);
   T* out = reinterpret_cast<T*>(kp.out);
   const int hw = p_hout * p_wout;
-  using V4 = typename Vec4<T>::type;
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    const int pp = pn0 + wn * 64 + nt * 16 + lrow;
+  for (int nt = 0; nt < NT; ++nt) {
+    const int pp = pn0 + wn * 16 * NT + nt * 16 + lrow;
     if (pp >= p_P) continue;
     const int n = pp / hw;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const int co = cm0 + wm * 64 + mt * 16 + lq * 4;
+    for (int mt = 0; mt < MT; ++mt) {
+      const int co = cm0 + wm * 16 * MT + mt * 16 + lq * 4;
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[mt][nt][r];
@@ -275,28 +298,95 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
   }
 }
 
-template <typename T, int WM, int WN>
-int launch_conv(const ConvP& p, hipStream_t st) {
-  constexpr int BM = 64 * WM, BN = 64 * WN;
+// split-K second pass: fixed-order sum of the f32 slabs + the conv epilogue
+template <typename T>
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvP kp) {
+  const long long total = (long long)kp.P * (kp.cout / 4);
+  const T* res = reinterpret_cast<const T*>(kp.residual);
+  const T* bnc = reinterpret_cast<const T*>(kp.bias_nc);
+  T* out = reinterpret_cast<T*>(kp.out);
+  const int hw = kp.hout * kp.wout, c4 = kp.cout / 4;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int pp = (int)(idx / c4), co = (int)(idx - (long long)pp * c4) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < kp.splits; ++s) {
+      const float4 q = *reinterpret_cast<const float4*>(kp.partial + ((size_t)s * kp.P + pp) * kp.cout + co);
+      v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+    }
+    if (kp.bias) {
+      const float4 bv = *reinterpret_cast<const float4*>(kp.bias + co);
+      v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+    }
+    if (bnc) {
+      float f[4];
+      Vec4<T>::load(bnc + (size_t)(pp / hw) * kp.ld_bias_nc + co, f);
+      for (int r = 0; r < 4; ++r) v[r] += f[r];
+    }
+    if (res) {
+      float f[4];
+      Vec4<T>::load(res + (size_t)pp * kp.cout + co, f);
+      for (int r = 0; r < 4; ++r) v[r] += f[r];
+    }
+    for (int r = 0; r < 4; ++r) v[r] *= kp.out_scale;
+    Vec4<T>::store(out + (size_t)pp * kp.cout + co, v);
+  }
+}
+
+template <typename T, int MT, int NT, int WM, int WN>
+int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes) {
+  constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
+  constexpr int BKE = 8 * ET<T>::EPV;
   ConvP q = p;
   q.n_ct = p.cout / BM;
   q.n_pt = (p.P + BN - 1) / BN;
+  const int nblk = q.n_ct * q.n_pt;
+  const int nk = p.taps * (p.cin / BKE);
+  // split-K when the tile grid cannot fill the chip (2 resident blocks per CU x 256 CUs)
+  int splits = 1;
+  if (ws != nullptr && nblk < 384 && nk >= 16) {
+    splits = (512 + nblk - 1) / nblk;
+    if (splits > 8) splits = 8;
+    if (splits > nk / 8) splits = nk / 8;
+    while (splits > 1 && (long long)splits * p.P * p.cout * 4 > ws_bytes) --splits;
+    if (splits < 1) splits = 1;
+  }
+  q.ks_per_split = (nk + splits - 1) / splits;
+  splits = (nk + q.ks_per_split - 1) / q.ks_per_split;       // no empty split
+  q.splits = splits;
+  q.partial = ws;
   const size_t lds = 2 * (size_t)(BM + BN) * 128;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, WM, WN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, MT, NT, WM, WN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<T, WM, WN>), dim3(q.n_ct * q.n_pt), dim3(256), lds, st, q);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, MT, NT, WM, WN>), dim3(nblk, splits), dim3(256), lds, st, q);
   DTS_CHECK_LAUNCH("dts_conv2d");
+  if (splits > 1) {
+    long long g = ((long long)p.P * (p.cout / 4) + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL((conv_splitk_reduce_kernel<T>), dim3((int)g), dim3(256), 0, st, q);
+    DTS_CHECK_LAUNCH("dts_conv2d(split-K reduce)");
+  }
   return DTS_OK;
 }
 
+int g_tile_override = -1;      // DTS_CONV_TILE=64|128|192 (tuning aid; only honoured when it divides cout)
+
 template <typename T>
-int conv_dispatch(const ConvP& p, hipStream_t st) {
-  if (p.cout % 128 == 0 && p.P >= 128 * 256) return launch_conv<T, 2, 2>(p, st);
-  return launch_conv<T, 1, 4>(p, st);
+int conv_dispatch(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes) {
+  if (g_tile_override < 0) {
+    const char* e = getenv("DTS_CONV_TILE");
+    g_tile_override = e ? atoi(e) : 0;
+  }
+  int tile = (p.cout % 192 == 0) ? 192 : (p.cout % 128 == 0 ? 128 : 64);    // measured: tools/conv_bench.py
+  if (g_tile_override > 0 && p.cout % g_tile_override == 0) tile = g_tile_override;
+  switch (tile) {
+    case 192: return launch_conv<T, 6, 4, 2, 2>(p, st, ws, ws_bytes);
+    case 128: return launch_conv<T, 4, 4, 2, 2>(p, st, ws, ws_bytes);
+    default: return launch_conv<T, 4, 4, 1, 4>(p, st, ws, ws_bytes);
+  }
 }
 
 }  // namespace
@@ -323,7 +413,9 @@ extern "C" int dts_conv2d(const dts_conv_args* a, dts_stream s) {
   const long long P = (long long)p.n * p.hout * p.wout;
   DTS_CHECK_ARG(P < (1ll << 30), "dts_conv2d: too many pixels");
   p.P = (int)P; p.out_scale = a->out_scale; p.n_ct = p.n_pt = 0;
+  p.splits = 1; p.ks_per_split = 0; p.partial = nullptr;
+  DTS_CHECK_ARG(a->workspace == nullptr || ((uintptr_t)a->workspace % 16 == 0 && a->workspace_bytes >= 0), "dts_conv2d: workspace");
   hipStream_t st = to_stream(s);
-  DTS_DISPATCH_DTYPE(a->dtype, return conv_dispatch<T>(p, st));
+  DTS_DISPATCH_DTYPE(a->dtype, return conv_dispatch<T>(p, st, (float*)a->workspace, (long long)a->workspace_bytes));
   return DTS_OK;
 }

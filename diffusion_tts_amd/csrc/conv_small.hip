@@ -7,28 +7,28 @@
 namespace {
 
 // x f32 NCHW [n][3][h][w]; w f32 [cout][3][3][3]; out NHWC T
+// One thread per output pixel: its 27 inputs are loaded once into registers, then it walks the cout chunks; the
+// weight reads are wave-uniform (LDS broadcast), the stores are 16 B per lane.
 template <typename T>
 __global__ __launch_bounds__(256) void conv_in3_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, T* __restrict__ out, int n_total, int h,
                                                         int wd, int cout) {
   constexpr int EPV = ET<T>::EPV;
-  extern __shared__ float sw[];                       // [27][cout] (tap-major so a chunk of couts is contiguous)
+  extern __shared__ float sw[];                       // [27][cout] + [cout] bias
   for (int i = threadIdx.x; i < 27 * cout; i += blockDim.x) {
     const int co = i / 27, k = i - co * 27;
     sw[k * cout + co] = w[i];
   }
+  for (int i = threadIdx.x; i < cout; i += blockDim.x) sw[27 * cout + i] = bias ? bias[i] : 0.f;
   __syncthreads();
   const int nchunk = cout / EPV;
-  const long long total = (long long)n_total * h * wd * nchunk;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int chunk = (int)(idx % nchunk);
-    long long pix = idx / nchunk;
+  const long long npix = (long long)n_total * h * wd;
+  for (long long pix0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; pix0 < npix; pix0 += (long long)gridDim.x * blockDim.x) {
+    long long pix = pix0;
     const int xo = (int)(pix % wd); pix /= wd;
     const int yo = (int)(pix % h);
     const int n = (int)(pix / h);
-    float acc[EPV];
-#pragma unroll
-    for (int e = 0; e < EPV; ++e) acc[e] = 0.f;
+    float in[27];
 #pragma unroll
     for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
@@ -38,15 +38,21 @@ __global__ __launch_bounds__(256) void conv_in3_kernel(const float* __restrict__
           const int yy = yo + kh - 1, xx = xo + kw - 1;
           float v = 0.f;
           if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)wd) v = x[(((size_t)n * 3 + ci) * h + yy) * wd + xx];
-          const float* wr = sw + (ci * 9 + kh * 3 + kw) * cout + chunk * EPV;
-#pragma unroll
-          for (int e = 0; e < EPV; ++e) acc[e] += v * wr[e];
+          in[ci * 9 + kh * 3 + kw] = v;
         }
-    if (bias) {
+    T* orow = out + (size_t)pix0 * cout;
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+      float acc[EPV];
 #pragma unroll
-      for (int e = 0; e < EPV; ++e) acc[e] += bias[chunk * EPV + e];
+      for (int e = 0; e < EPV; ++e) acc[e] = sw[27 * cout + chunk * EPV + e];
+#pragma unroll
+      for (int k = 0; k < 27; ++k) {
+        const float* wr = sw + k * cout + chunk * EPV;
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) acc[e] += in[k] * wr[e];
+      }
+      *reinterpret_cast<uint4*>(orow + chunk * EPV) = pack16<T>(acc);
     }
-    *reinterpret_cast<uint4*>(out + (((size_t)n * h + yo) * wd + xo) * cout + chunk * EPV) = pack16<T>(acc);
   }
 }
 
@@ -115,10 +121,10 @@ extern "C" int dts_conv_in3(const float* x, const float* w, const float* bias, v
   DTS_CHECK_ARG(n > 0 && h > 0 && w_ > 0 && cout % 8 == 0 && cout <= 512, "dts_conv_in3: bad shape (cout=%d)", cout);
   hipStream_t st = to_stream(s);
   DTS_DISPATCH_DTYPE(dtype, {
-    const long long total = (long long)n * h * w_ * (cout / ET<T>::EPV);
+    const long long total = (long long)n * h * w_;
     long long g = (total + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL((conv_in3_kernel<T>), dim3((int)g), dim3(256), 27 * cout * sizeof(float), st, x, w, bias, (T*)out, n, h, w_,
+    hipLaunchKernelGGL((conv_in3_kernel<T>), dim3((int)g), dim3(256), 28 * cout * sizeof(float), st, x, w, bias, (T*)out, n, h, w_,
                        cout);
     DTS_CHECK_LAUNCH("dts_conv_in3");
   });

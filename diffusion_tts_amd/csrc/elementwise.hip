@@ -168,7 +168,8 @@ __global__ void u8_to_unit_kernel(const uint8_t* __restrict__ img, float* __rest
 }
 
 // ---- K7 ------------------------------------------------------------------------------------------------
-// one wave per output column; the wave keeps w[n][:] in registers across all m rows
+// one wave per output column; rows are processed 8 at a time so their loads and reductions overlap
+// (one row at a time was latency-bound: ~2 us of dependent L2 round trip + shuffles per row)
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ y, int ldy, int m, int k,
                                                       int n, int act_in, int act_out, int accumulate) {
@@ -176,21 +177,35 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
   const int lane = threadIdx.x & 63;
   if (col >= n) return;
   const float* wr = w + (size_t)col * k;
-  for (int row = 0; row < m; ++row) {
-    const float* xr = x + (size_t)row * ldx;
-    float acc = 0.f;
+  constexpr int RB = 8;
+  for (int row0 = 0; row0 < m; row0 += RB) {
+    float acc[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = 0.f;
     for (int j = lane; j < k; j += 64) {
-      float xv = xr[j];
-      if (act_in) xv = silu_f(xv);
-      acc += xv * wr[j];
+      const float wv = wr[j];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        if (row0 + r < m) {
+          float xv = x[(size_t)(row0 + r) * ldx + j];
+          if (act_in) xv = silu_f(xv);
+          acc[r] += xv * wv;
+        }
+      }
     }
-    acc = wave_sum(acc);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = wave_sum(acc[r]);
     if (lane == 0) {
-      float v = acc + (bias ? bias[col] : 0.f);
-      float* o = y + (size_t)row * ldy + col;
-      if (accumulate) v += *o;
-      if (act_out) v = silu_f(v);
-      *o = v;
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        if (row0 + r < m) {
+          float v = acc[r] + (bias ? bias[col] : 0.f);
+          float* o = y + (size_t)(row0 + r) * ldy + col;
+          if (accumulate) v += *o;
+          if (act_out) v = silu_f(v);
+          *o = v;
+        }
+      }
     }
   }
 }

@@ -80,6 +80,18 @@ def pack_conv_weight(w, dtype, out_perm=None):
 
 
 # ---- convolution --------------------------------------------------------------------------------
+_CONV_WS = {}
+CONV_WS_BYTES = 96 << 20        # split-K scratch per device (covers 8 splits of the 8x8 / 16x16 ADM levels at N=64)
+
+
+def _conv_workspace(device):
+    key = (device.type, device.index)
+    ws = _CONV_WS.get(key)
+    if ws is None:
+        ws = _CONV_WS[key] = torch.empty(CONV_WS_BYTES, dtype=torch.uint8, device=device)
+    return ws
+
+
 def conv2d(x1, w, bias=None, *, x2=None, bias_nc=None, residual=None, up=False, out_scale=1.0, out=None):
     n, hin, win, c1 = x1.shape
     c2 = 0 if x2 is None else x2.shape[-1]
@@ -101,6 +113,8 @@ def conv2d(x1, w, bias=None, *, x2=None, bias_nc=None, residual=None, up=False, 
     a.out = _ptr(out, 'out', x1.dtype)
     a.n, a.hin, a.win, a.cout, a.ksize = n, hin, win, cout, kh
     a.up, a.out_scale, a.dtype = int(up), float(out_scale), dt_code(x1.dtype)
+    ws = _conv_workspace(x1.device)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     _call('dts_conv2d', C.byref(a))
     return out
 

@@ -59,6 +59,8 @@ typedef struct dts_conv_args {
   int32_t up;                     /* 1: nearest 2x upsample of the input fused into the gather (networks.py:82-83) */
   float out_scale;                /* out = (conv + bias + bias_nc + residual) * out_scale  (networks.py:179,186 skip_scale) */
   int32_t dtype;
+  void* workspace;                /* optional scratch (16-byte aligned) for split-K partial sums; NULL disables split-K */
+  int64_t workspace_bytes;
 } dts_conv_args;
 int dts_conv2d(const dts_conv_args* a, dts_stream s);
 

@@ -250,7 +250,7 @@ def main():
         ('rejection_ddpmpp', 'ddpmpp_tiny', 'brightness', 'REJECTION_SAMPLING', dict(N=4), 6, 1),
         ('epsgreedy_adm_bright', 'adm_tiny', 'brightness', 'EPS_GREEDY', dict(N=4, K=2, lambda_param=0.15, eps=0.4), 6, 2),
         ('epsgreedy_adm_imagenet', 'adm_tiny', 'imagenet', 'EPS_GREEDY', dict(N=4, K=2, lambda_param=0.15, eps=0.4), 6, 1),
-        ('zeroorder_adm', 'adm_tiny', 'imagenet', 'ZERO_ORDER', dict(N=4, K=2, lambda_param=0.15, eps=0.0), 6, 1),
+        ('zeroorder_adm', 'adm_tiny', 'brightness', 'ZERO_ORDER', dict(N=4, K=2, lambda_param=0.15, eps=0.0), 6, 1),
         ('mcts_adm', 'adm_tiny', 'brightness', 'MCTS', dict(N=2, S=4), 6, 2),
         ('beam_adm', 'adm_tiny', 'brightness', 'BEAM_SEARCH', dict(B=2, N=2), 6, 1),
     ]
@@ -258,8 +258,30 @@ def main():
     for case, netname, scname, method, params, steps, batch in cases:
         lat, lab = (latents1, lab1) if batch == 1 else (latents2, lab2)
         scorer = bright if scname == 'brightness' else inet
-        lg, sl, png, err = run_ref_search(nets[netname], scorer, lat, lab, method, params, steps)
-        meta = dict(net=netname, scorer=scname, method=method, params=params, num_steps=steps, batch=batch,
+        # A decision whose top-2 reward gap is below fp32 noise (or below one truncation flip of the uint8 image,
+        # ~1e-5 for brightness) is numerically undetermined even between two runs of the reference on different
+        # BLAS builds.  Pick the first search seed for which every decision is an exact tie (first-max rule) or has a
+        # gap >= MARGIN, so "same selected indices" is a meaningful parity statement.
+        MARGIN = 4e-5
+        for seed in range(64):
+            lg, sl, png, err = run_ref_search(nets[netname], scorer, lat, lab, method, params, steps, seed=seed)
+            if err is not None:
+                break
+            gaps = []
+            if method in ('EPS_GREEDY', 'ZERO_ORDER'):
+                for imgs, sc in sl.calls[:-1]:
+                    v = sc.reshape(params['N'], batch)
+                    t = v.sort(dim=0, descending=True).values
+                    gaps += (t[0] - t[1]).tolist()
+            elif method == 'REJECTION_SAMPLING':
+                t = sl.calls[0][1].reshape(batch, -1).sort(dim=1, descending=True).values
+                gaps += (t[:, 0] - t[:, 1]).tolist()
+            if all(g == 0 or g >= MARGIN for g in gaps):
+                break
+        else:
+            raise RuntimeError(f'{case}: no seed with safe decision margins')
+        meta = dict(net=netname, scorer=scname, method=method, params=params, num_steps=steps, batch=batch, seed=seed,
+                    min_gap=(min([g for g in gaps if g > 0]) if err is None and any(g > 0 for g in gaps) else None),
                     error=err, net_calls=len(lg.calls), net_rows=int(sum(c[0].shape[0] for c in lg.calls)),
                     scorer_calls=len(sl.calls))
         case_meta[case] = meta

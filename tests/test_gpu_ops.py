@@ -55,7 +55,7 @@ def test_layout_roundtrip(ops, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('case', ['3x3', '1x1', 'up', 'cat', 'full_epilogue', 'ragged', 'wide'])
+@pytest.mark.parametrize('case', ['3x3', '1x1', 'up', 'cat', 'full_epilogue', 'ragged', 'wide', 'tile192', 'tile576', 'splitk', 'splitk_full'])
 def test_conv2d(ops, dtype, case):
     gen = g(1)
     n, h, w, c1, c2, cout, k, up = 2, 8, 8, 64, 0, 64, 3, False
@@ -69,6 +69,12 @@ def test_conv2d(ops, dtype, case):
         n, h, w = 3, 5, 7                 # 105 pixels: partial pixel tile
     if case == 'wide':
         n, h, w, c1, cout = 8, 32, 32, 128, 128          # 8192 pixels: exercises the XCD remap; below 2x2-tile threshold
+    if case == 'tile192':
+        cout = 192                         # 192x128 block tile
+    if case == 'tile576':
+        n, h, w, c1, cout = 1, 16, 16, 128, 576
+    if case in ('splitk', 'splitk_full'):
+        n, h, w, c1, cout = 1, 8, 8, 256, 128            # 1 tile, 36+ K-steps: split-K with f32 slabs + reduce kernel
     x1 = q(torch.randn(n, c1, h, w, generator=gen), dtype)
     x2 = q(torch.randn(n, c2, h, w, generator=gen), dtype) if c2 else None
     wt = q(torch.randn(cout, c1 + c2, k, k, generator=gen) / math.sqrt((c1 + c2) * k * k), dtype)
@@ -76,7 +82,7 @@ def test_conv2d(ops, dtype, case):
     xin = x1 if x2 is None else torch.cat([x1, x2], 1)
     ref = onet.conv2d(xin, wt, bias, up=up)
     kw = {}
-    if case == 'full_epilogue':
+    if case in ('full_epilogue', 'splitk_full'):
         bnc = q(torch.randn(n, cout, generator=gen), dtype)
         res = q(torch.randn(n, cout, h, w, generator=gen), dtype)
         ref = (ref + bnc[:, :, None, None] + res) * 0.70710678

@@ -97,7 +97,7 @@ def run_case(pkg, golden, manifest, case, dtype):
     lat, lab = T(golden[f'search_latents{b}']), T(golden[f'search_lab{b}'])
     sm = pkg['sampler']
     np.random.seed(0)
-    res = sm.generate_image_grid(net, None, lat, lab, seed=0, gridw=b, gridh=1, device=torch.device(DEV),
+    res = sm.generate_image_grid(net, None, lat, lab, seed=meta['seed'], gridw=b, gridh=1, device=torch.device(DEV),
                                  num_steps=meta['num_steps'], S_churn=40, S_min=0.05, S_max=50, S_noise=1.003,
                                  sampling_method=getattr(sm.SamplingMethod, meta['method']),
                                  sampling_params=dict(scorer=scorer, **meta['params']),

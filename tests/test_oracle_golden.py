@@ -61,7 +61,7 @@ def _run_case(golden, manifest, case):
     method = {'NAIVE': 'naive', 'REJECTION_SAMPLING': 'rejection', 'EPS_GREEDY': 'eps_greedy',
               'ZERO_ORDER': 'zero_order', 'MCTS': 'mcts', 'BEAM_SEARCH': 'beam'}[meta['method']]
     np.random.seed(0)
-    res = osamp.search(net, lat, lab, method=method, params=dict(scorer=scorer, **meta['params']), seed=0,
+    res = osamp.search(net, lat, lab, method=method, params=dict(scorer=scorer, **meta['params']), seed=meta['seed'],
                        num_steps=meta['num_steps'], S_churn=40, S_min=0.05, S_max=50, S_noise=1.003,
                        scale_fn=seed0_scale)
     return meta, net, res
