@@ -1,0 +1,120 @@
+"""Unified CLI of the MI355X-native noise-trajectory-search path -- same flags as the reference's main.py:84-97.
+
+    python main.py --backend edm --scorer imagenet --method eps_greedy --N 64 --K 4
+    python main.py --backend edm --scorer brightness --method rejection --N 16 --network random:ddpmpp_cifar10
+
+Arguments (verbatim from the reference):
+    --backend   : 'sd' or 'edm' (required)
+    --scorer    : 'brightness', 'compressibility', 'clip', or 'imagenet' (required)
+    --method    : naive | rejection | beam | mcts | zero_order | eps_greedy (default naive)
+    --prompt, --output, --N, --lambda_, --eps, --K, --B, --S, --seed, --device
+Additions (the reference hard-codes a checkpoint URL, main.py:157-158; there is no network here):
+    --network   : 'random:adm_imagenet64[:seed]' (default), 'random:ddpmpp_cifar10[:seed]', or a .pt bundle
+    --dtype     : bf16 (default) | f16 | f32 (parity mode)
+Multi-GPU: launch with `python -m torch.distributed.run --nproc-per-node N main.py ...`; the N candidates of every
+search iteration are sharded across the ranks (diffusion_tts_amd/parallel.py).
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def get_scorer(backend, scorer_name, device):
+    """main.py:60-71 of the reference."""
+    from diffusion_tts_amd import scorers as S
+    if scorer_name == 'brightness':
+        return S.BrightnessScorer(dtype=torch.float32)
+    if scorer_name == 'compressibility':
+        return S.CompressibilityScorer(dtype=torch.float32)
+    if scorer_name == 'imagenet' and backend == 'edm':
+        return S.ImageNetScorer(dtype=torch.float32, device=device)
+    if scorer_name == 'clip' and backend == 'sd':
+        raise ValueError('the CLIP scorer needs the SD backend, which is not built yet (see below)')
+    raise ValueError(f"Unknown or invalid scorer '{scorer_name}' for backend '{backend}'")
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser(description='Unified Diffusion Image Generator (EDM/SD), MI355X-native hot path',
+                                     formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    parser.add_argument('--backend', type=str, choices=['edm', 'sd'], required=True, help='Backend: edm or sd')
+    parser.add_argument('--scorer', type=str, choices=['brightness', 'compressibility', 'clip', 'imagenet'], required=True,
+                        help='Scorer name')
+    parser.add_argument('--method', type=str, default='naive',
+                        help='Sampling method (naive, rejection, beam, mcts, zero_order, eps_greedy)')
+    parser.add_argument('--prompt', type=str, default='YOUR PROMPT HERE', help='Prompt for SD')
+    parser.add_argument('--output', type=str, default=None, help='Output filename (default: auto)')
+    parser.add_argument('--N', type=int, default=4, help='Master param N')
+    parser.add_argument('--lambda_', type=float, default=0.15, help='Master param lambda')
+    parser.add_argument('--eps', type=float, default=0.4, help='Master param eps')
+    parser.add_argument('--K', type=int, default=20, help='Master param K')
+    parser.add_argument('--B', type=int, default=2, help='Master param B')
+    parser.add_argument('--S', type=int, default=8, help='Master param S')
+    parser.add_argument('--seed', type=int, default=0, help='Random seed')
+    parser.add_argument('--device', type=str, default='cuda', help='Device')
+    parser.add_argument('--network', type=str, default='random:adm_imagenet64', help='EDM network spec (see module docstring)')
+    parser.add_argument('--dtype', type=str, default='bf16', choices=['bf16', 'f16', 'f32'], help='activation dtype')
+    args = parser.parse_args(argv)
+
+    if args.backend == 'sd' and args.scorer == 'imagenet':
+        raise ValueError('imagenet scorer is only available for edm backend')
+    if args.backend == 'edm' and args.scorer == 'clip':
+        raise ValueError('clip scorer is only available for sd backend')
+    if args.backend == 'sd':
+        raise NotImplementedError(
+            'SD backend: the search loop needs the (vendored, modified) diffusers U-Net/VAE, which is not installed here; '
+            'the fused DDIM candidate step it would call exists (dts_ddim_candidates); see DESIGN.md "out of scope".')
+    if not str(args.device).startswith('cuda'):
+        raise RuntimeError(f"--device {args.device}: this build is the GPU path; the CPU path is the reference itself "
+                           f"(its restatement lives in oracle/ as test infrastructure)")
+
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    device = torch.device('cuda', local if world > 1 else (torch.device(args.device).index or 0))
+    torch.cuda.set_device(device)
+
+    from diffusion_tts_amd.sampler import SamplingMethod, generate_image_grid, load_network
+    dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[args.dtype]
+    scorer = get_scorer('edm', args.scorer, device)
+    net = load_network(args.network, device=device, dtype=dtype)
+    num_images = 1
+    r = net.img_resolution
+    latents = torch.randn([num_images, net.img_channels, r, r])                       # drawn before seeding, as main.py:161
+    class_labels = torch.eye(net.label_dim)[torch.randint(net.label_dim, size=[num_images])] if net.label_dim else None
+    if world > 1:                                                                      # replicate the unseeded draws
+        latents, class_labels = latents.to(device), None if class_labels is None else class_labels.to(device)
+        dist.broadcast(latents, 0)
+        if class_labels is not None:
+            dist.broadcast(class_labels, 0)
+        latents, class_labels = latents.cpu(), None if class_labels is None else class_labels.cpu()
+    method_map = {'naive': SamplingMethod.NAIVE, 'rejection': SamplingMethod.REJECTION_SAMPLING,
+                  'beam': SamplingMethod.BEAM_SEARCH, 'mcts': SamplingMethod.MCTS,
+                  'zero_order': SamplingMethod.ZERO_ORDER, 'eps_greedy': SamplingMethod.EPS_GREEDY}
+    if args.method not in method_map:
+        raise ValueError(f'Unknown method: {args.method}')
+    sampling_params = {'scorer': scorer}
+    if args.method in ['rejection', 'zero_order', 'eps_greedy', 'beam', 'mcts']:
+        sampling_params.update(N=args.N, K=args.K, lambda_param=args.lambda_, eps=args.eps, B=args.B, S=args.S)
+    outname = args.output or f'edm_{args.method}_{args.scorer}.png'
+    res = generate_image_grid(net, outname, latents, class_labels, seed=args.seed, gridw=1, gridh=1, device=device,
+                              num_steps=18, S_churn=40, S_min=0.05, S_max=50, S_noise=1.003,
+                              sampling_method=method_map[args.method], sampling_params=sampling_params, compute_dtype=dtype)
+    if int(os.environ.get('RANK', '0')) == 0:
+        print(f'\n[EDM] Saved: {outname}  (denoiser rows: {res["net_rows"]}, reward collectives: {res["collectives"]})\n')
+    if world > 1:
+        dist.destroy_process_group()
+    return res
+
+
+if __name__ == '__main__':
+    main()

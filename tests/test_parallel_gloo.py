@@ -1,0 +1,71 @@
+"""CPU, world_size 2 over gloo: the candidate-sharding layer (parallel.CandidateShards) used by the N>1 path.
+Checks the partition, the ONE reward all-gather per iteration (even and ragged N), that every rank takes the same
+first-max argmax as the unsharded loop, and the owner broadcast used by rejection sampling."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from diffusion_tts_amd.parallel import CandidateShards
+        sh = CandidateShards()
+        assert (sh.rank, sh.world) == (rank, world)
+        out = {}
+        for N, B in ((8, 1), (7, 2), (64, 1), (3, 1)):
+            spans = [sh.span(N, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == N and all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            g = torch.Generator().manual_seed(100 + N)                  # replicated "host RNG"
+            full = torch.rand(N, B, generator=g)                        # rewards of all candidates (candidate-major)
+            full[N // 2] = full.max() + 0.0                             # make an exact tie with the max -> first-max rule matters
+            lo, hi = sh.span(N)
+            before = sh.collectives
+            got = sh.gather_rewards(full[lo:hi].reshape(-1).clone(), N, B)
+            assert sh.collectives == before + 1                        # exactly one collective per search iteration
+            assert torch.equal(got.reshape(N, B), full)
+            best = got.reshape(N, B).argmax(dim=0)
+            assert torch.equal(best, full.argmax(dim=0))
+            out[(N, B)] = best.tolist()
+            # rejection: the winner's image goes once from its owner to everyone
+            win = int(best[0])
+            img = torch.full((3, 4, 4), float(win)) if lo <= win < hi else torch.zeros(3, 4, 4)
+            img = sh.broadcast_from_owner(img, win, N)
+            assert torch.equal(img, torch.full((3, 4, 4), float(win)))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_candidate_sharding_world2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res = dict(res)
+    assert res[0] == res[1]                                              # identical survivor on every rank
+
+
+def test_single_process_is_a_noop():
+    from diffusion_tts_amd.parallel import CandidateShards
+    sh = CandidateShards()
+    assert (sh.rank, sh.world) == (0, 1) and sh.span(5) == (0, 5)
+    x = torch.arange(5.0)
+    assert sh.gather_rewards(x, 5, 1) is x and sh.collectives == 0
