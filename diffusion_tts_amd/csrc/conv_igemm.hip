@@ -70,6 +70,7 @@ template <> struct Mma<float> {
 template <typename T> struct Vec4;
 template <> struct Vec4<float> {
   using type = float4;
+  static __device__ __forceinline__ void unpack(const float4& v, float* f) { f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
   static __device__ __forceinline__ void load(const float* p, float* f) {
     const float4 v = *reinterpret_cast<const float4*>(p);
     f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
@@ -80,6 +81,10 @@ template <> struct Vec4<float> {
 };
 template <> struct Vec4<bf16_t> {
   using type = uint2;
+  static __device__ __forceinline__ void unpack(const uint2& v, float* f) {
+    f[0] = bf16_bits_to_f32(v.x & 0xffffu); f[1] = bf16_bits_to_f32(v.x >> 16);
+    f[2] = bf16_bits_to_f32(v.y & 0xffffu); f[3] = bf16_bits_to_f32(v.y >> 16);
+  }
   static __device__ __forceinline__ void load(const bf16_t* p, float* f) {
     const uint2 v = *reinterpret_cast<const uint2*>(p);
     f[0] = bf16_bits_to_f32(v.x & 0xffffu); f[1] = bf16_bits_to_f32(v.x >> 16);
@@ -92,6 +97,10 @@ template <> struct Vec4<bf16_t> {
 };
 template <> struct Vec4<f16_t> {
   using type = uint2;
+  static __device__ __forceinline__ void unpack(const uint2& v, float* f) {
+    f[0] = f16_bits_to_f32(v.x & 0xffffu); f[1] = f16_bits_to_f32(v.x >> 16);
+    f[2] = f16_bits_to_f32(v.y & 0xffffu); f[3] = f16_bits_to_f32(v.y >> 16);
+  }
   static __device__ __forceinline__ void load(const f16_t* p, float* f) {
     const uint2 v = *reinterpret_cast<const uint2*>(p);
     f[0] = f16_bits_to_f32(v.x & 0xffffu); f[1] = f16_bits_to_f32(v.x >> 16);
@@ -119,21 +128,24 @@ __device__ __forceinline__ void glds16(const char* g, uint32_t lds_off) {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
-template <typename T, int MT, int NT, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
+template <typename T, int MT, int NT, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_igemm_kernel(const ConvP kp) {
   const char* const p_x1 = kp.x1; const char* const p_x2 = kp.x2; const char* const p_w = kp.w;
   const int p_c1 = kp.c1, p_c2 = kp.c2, p_cin = kp.cin, p_hin = kp.hin, p_win = kp.win, p_hout = kp.hout, p_wout = kp.wout;
   const int p_taps = kp.taps, p_up = kp.up, p_P = kp.P, p_cout = kp.cout, p_n_ct = kp.n_ct, p_n_pt = kp.n_pt;
-  static_assert(WM * WN == 4, "4 waves per block");
+  constexpr int NW = WM * WN;              // waves per block (4: two blocks per CU; 8: one block per CU, 3-stage ring)
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves per block");
+  static_assert(STAGES == 2 || STAGES == 3, "2- or 3-stage LDS ring");
+  constexpr int SLAB = 8 * NW;             // rows staged by one wave-instruction round of the whole block
   constexpr int BM = 16 * MT * WM;         // couts per block
   constexpr int BN = 16 * NT * WN;         // pixels per block
   constexpr int EPV = ET<T>::EPV;
   constexpr int BKE = 8 * EPV;             // K elements per step (128 bytes)
   constexpr int ES = 16 / EPV;             // element size
-  constexpr int RA = BM / 32;              // A wave-instructions (8 rows each) per wave
-  constexpr int RB = BN / 32;              // B wave-instructions per wave
-  static_assert(BM % 32 == 0 && BN % 32 == 0, "tile rows must split over 4 waves x 8 rows");
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  constexpr int RA = BM / SLAB;            // A wave-instructions (8 rows each) per wave
+  constexpr int RB = BN / SLAB;            // B wave-instructions per wave
+  static_assert(BM % SLAB == 0 && BN % SLAB == 0, "tile rows must split over the waves x 8 rows");
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   // ---- XCD-aware tile mapping: blocks b, b+8, b+16.. (same XCD under round-robin dispatch) walk the
@@ -155,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
   int pix_n[RB], pix_hw[RB];
 #pragma unroll
   for (int j = 0; j < RB; ++j) {
-    const int pp = pn0 + r0 + 32 * j;
+    const int pp = pn0 + r0 + SLAB * j;
     if (pp < p_P) {
       const int hw = p_hout * p_wout;
       const int n = pp / hw, rem = pp - n * hw;
@@ -173,11 +185,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
   const int ks_begin = blockIdx.y * kp.ks_per_split;
   const int ks_end = min(nk_all, ks_begin + kp.ks_per_split);
 
-  int src_pix[RB];                                     // source pixel index (or -1) for the current tap
+  int src_pix[RB];                                     // source pixel index (or -1) for the tap being issued
   const int schunk = (chunk ^ (r0 & 7)) * 16;          // source chunk of this lane's (linear) LDS slot
   const char* wsrc = p_w + ((size_t)(cm0 + r0) * K) * ES + schunk;
   const char* zsrc = reinterpret_cast<const char*>(g_zero16);
-  // LDS byte address of this wave's 8 rows inside each 32-row slab (wave-uniform by construction)
+  // LDS byte address of this wave's 8 rows inside each slab (wave-uniform by construction)
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const uint32_t wave_rows = __builtin_amdgcn_readfirstlane(lds_base + (tid >> 6) * 8 * 128);
 
@@ -193,16 +205,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
   }
 #define ISSUE_TILE(buf_, ks_, ci0_)                                                                           \
   {                                                                                                           \
-    const uint32_t sa_ = wave_rows + (buf_) * (A_BYTES + B_BYTES);                                            \
+    const uint32_t sa_ = wave_rows + (buf_) * STAGE_BYTES;                                                    \
     const uint32_t sb_ = sa_ + A_BYTES;                                                                       \
     const char* wp = wsrc + (size_t)(ks_) * BKE * ES;                                                         \
-    _Pragma("unroll") for (int j = 0; j < RA; ++j) glds16(wp + (size_t)(32 * j) * K * ES, sa_ + j * 32 * 128); \
+    _Pragma("unroll") for (int j = 0; j < RA; ++j) glds16(wp + (size_t)(SLAB * j) * K * ES, sa_ + j * SLAB * 128); \
     const char* xb; int cs, cofs;                                                                             \
     if ((ci0_) < p_c1) { xb = p_x1; cs = p_c1; cofs = (ci0_); } else { xb = p_x2; cs = p_c2; cofs = (ci0_) - p_c1; } \
     _Pragma("unroll") for (int j = 0; j < RB; ++j) {                                                          \
       const char* src = src_pix[j] >= 0 ? xb + ((size_t)src_pix[j] * cs + cofs) * ES + schunk : zsrc;         \
-      glds16(src, sb_ + j * 32 * 128);                                                                        \
+      glds16(src, sb_ + j * SLAB * 128);                                                                      \
     }                                                                                                         \
+  }
+#define ADVANCE_K()                                                                                           \
+  {                                                                                                           \
+    ci0 += BKE;                                                                                               \
+    if (ci0 == p_cin) { ci0 = 0; ++tap; SET_TAP(tap); }                                                       \
   }
 
   f32x4_t acc[MT][NT];
@@ -211,22 +228,34 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  // issue-side K state (tap, cin offset) runs STAGES-1 tiles ahead of the compute side
   int tap = ks_begin / steps_per_tap, ci0 = (ks_begin - tap * steps_per_tap) * BKE;
   SET_TAP(tap);
   ISSUE_TILE(0, ks_begin, ci0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (STAGES == 3) {
+    if (ks_begin + 1 < ks_end) {
+      ADVANCE_K();
+      ISSUE_TILE(1, ks_begin + 1, ci0);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RA + RB) : "memory");      // tile 0 landed, tile 1 in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __syncthreads();
 
   const int lrow = lane & 15, lq = lane >> 4;
+  int buf = 0;
   for (int ks = ks_begin; ks < ks_end; ++ks) {
-    const int buf = (ks - ks_begin) & 1;
-    if (ks + 1 < ks_end) {
-      ci0 += BKE;
-      if (ci0 == p_cin) { ci0 = 0; ++tap; SET_TAP(tap); }
-      ISSUE_TILE(buf ^ 1, ks + 1, ci0);            // buf^1 was last read in iteration ks-1 (barrier passed)
+    // the buffer written here was last read in iteration ks-1; every wave has passed that iteration's barrier
+    if (ks + STAGES - 1 < ks_end) {
+      ADVANCE_K();
+      const int wb = buf + STAGES - 1 >= STAGES ? buf - 1 : buf + STAGES - 1;
+      ISSUE_TILE(wb, ks + STAGES - 1, ci0);
     }
-    const char* sa = smem + buf * (A_BYTES + B_BYTES) + (wm * 16 * MT) * 128;
-    const char* sb = smem + buf * (A_BYTES + B_BYTES) + A_BYTES + (wn * 16 * NT) * 128;
+    const char* sa = smem + buf * STAGE_BYTES + (wm * 16 * MT) * 128;
+    const char* sb = smem + buf * STAGE_BYTES + A_BYTES + (wn * 16 * NT) * 128;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       uint4 fa[MT], fb[NT];
@@ -239,9 +268,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
     }
-    // tile ks+1 has landed (LDS-DMA is tracked by vmcnt) and this wave's LDS reads of tile ks have returned
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // next tile has landed (LDS-DMA completion is tracked by vmcnt; with 3 stages the tile after it stays in
+    // flight across the barrier) and this wave's LDS reads of the current tile have returned
+    if (STAGES == 3 && ks + 2 < ks_end) {
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(RA + RB) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
     __syncthreads();
+    buf = buf + 1 == STAGES ? 0 : buf + 1;
   }
 
   // ---- epilogue: lane holds couts co..co+3 of pixel pp for each (mt, nt): one 4-element vector load/store
@@ -260,34 +295,51 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
     }
     return;
   }
-  const T* res = reinterpret_cast<const T*>(kp.residual);
-  const T* bnc = reinterpret_cast<const T*>(kp.bias_nc);
-  T* out = reinterpret_cast<T*>(kp.out);
+  // All global reads of the epilogue are issued before the first store: `out` may alias nothing here, but the
+  // compiler cannot know that, and interleaved load/store pairs would serialise 24 memory round trips per lane.
+  const T* __restrict__ res = reinterpret_cast<const T*>(kp.residual);
+  const T* __restrict__ bnc = reinterpret_cast<const T*>(kp.bias_nc);
+  T* __restrict__ out = reinterpret_cast<T*>(kp.out);
   const int hw = p_hout * p_wout;
+  using V4 = typename Vec4<T>::type;
+  float4 bv[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int co = cm0 + wm * 16 * MT + mt * 16 + lq * 4;
+    bv[mt] = kp.bias ? *reinterpret_cast<const float4*>(kp.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  V4 rv[MT][NT], nv[MT][NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int pp = pn0 + wn * 16 * NT + nt * 16 + lrow;
+    const bool ok = pp < p_P;
+    const int n = ok ? pp / hw : 0;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int co = cm0 + wm * 16 * MT + mt * 16 + lq * 4;
+      if (res && ok) rv[mt][nt] = *reinterpret_cast<const V4*>(res + (size_t)pp * p_cout + co);
+      if (bnc && ok) nv[mt][nt] = *reinterpret_cast<const V4*>(bnc + (size_t)n * kp.ld_bias_nc + co);
+    }
+  }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int pp = pn0 + wn * 16 * NT + nt * 16 + lrow;
     if (pp >= p_P) continue;
-    const int n = pp / hw;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int co = cm0 + wm * 16 * MT + mt * 16 + lq * 4;
       float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[mt][nt][r];
-      if (kp.bias) {
-        const float4 bv = *reinterpret_cast<const float4*>(kp.bias + co);
-        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-      }
+      v[0] = acc[mt][nt][0] + bv[mt].x; v[1] = acc[mt][nt][1] + bv[mt].y;
+      v[2] = acc[mt][nt][2] + bv[mt].z; v[3] = acc[mt][nt][3] + bv[mt].w;
       if (bnc) {
         float f[4];
-        Vec4<T>::load(bnc + (size_t)n * kp.ld_bias_nc + co, f);
+        Vec4<T>::unpack(nv[mt][nt], f);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += f[r];
       }
       if (res) {
         float f[4];
-        Vec4<T>::load(res + (size_t)pp * p_cout + co, f);
+        Vec4<T>::unpack(rv[mt][nt], f);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += f[r];
       }
@@ -332,8 +384,9 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvP kp)
   }
 }
 
-template <typename T, int MT, int NT, int WM, int WN>
+template <typename T, int MT, int NT, int WM, int WN, int STAGES>
 int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes) {
+  constexpr int NW = WM * WN;
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
   constexpr int BKE = 8 * ET<T>::EPV;
   ConvP q = p;
@@ -341,10 +394,11 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes) {
   q.n_pt = (p.P + BN - 1) / BN;
   const int nblk = q.n_ct * q.n_pt;
   const int nk = p.taps * (p.cin / BKE);
-  // split-K when the tile grid cannot fill the chip (2 resident blocks per CU x 256 CUs)
+  // split-K when the tile grid cannot fill the chip (256 CUs x resident blocks per CU)
+  const int slots = NW == 4 ? 512 : 256;
   int splits = 1;
-  if (ws != nullptr && nblk < 384 && nk >= 16) {
-    splits = (512 + nblk - 1) / nblk;
+  if (ws != nullptr && nblk < (slots * 3) / 4 && nk >= 16) {
+    splits = (slots + nblk - 1) / nblk;
     if (splits > 8) splits = 8;
     if (splits > nk / 8) splits = nk / 8;
     while (splits > 1 && (long long)splits * p.P * p.cout * 4 > ws_bytes) --splits;
@@ -354,14 +408,14 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes) {
   splits = (nk + q.ks_per_split - 1) / q.ks_per_split;       // no empty split
   q.splits = splits;
   q.partial = ws;
-  const size_t lds = 2 * (size_t)(BM + BN) * 128;
+  const size_t lds = (size_t)STAGES * (BM + BN) * 128;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, MT, NT, WM, WN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, MT, NT, WM, WN, STAGES>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<T, MT, NT, WM, WN>), dim3(nblk, splits), dim3(256), lds, st, q);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, MT, NT, WM, WN, STAGES>), dim3(nblk, splits), dim3(64 * NW), lds, st, q);
   DTS_CHECK_LAUNCH("dts_conv2d");
   if (splits > 1) {
     long long g = ((long long)p.P * (p.cout / 4) + 255) / 256;
@@ -373,19 +427,27 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes) {
 }
 
 int g_tile_override = -1;      // DTS_CONV_TILE=64|128|192 (tuning aid; only honoured when it divides cout)
+int g_impl_override = -1;      // DTS_CONV_IMPL=4|8: 4-wave 2-stage blocks (2 per CU) or 8-wave 3-stage blocks (1 per CU)
 
 template <typename T>
 int conv_dispatch(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes) {
   if (g_tile_override < 0) {
     const char* e = getenv("DTS_CONV_TILE");
     g_tile_override = e ? atoi(e) : 0;
+    const char* f = getenv("DTS_CONV_IMPL");
+    g_impl_override = f ? atoi(f) : 0;
   }
   int tile = (p.cout % 192 == 0) ? 192 : (p.cout % 128 == 0 ? 128 : 64);    // measured: tools/conv_bench.py
   if (g_tile_override > 0 && p.cout % g_tile_override == 0) tile = g_tile_override;
+  const int impl = g_impl_override == 8 ? 8 : 4;
+  if (impl == 8 && tile != 64) {
+    if (tile == 192) return launch_conv<T, 6, 3, 2, 4, 3>(p, st, ws, ws_bytes);      // 192 x 192, 144 KB LDS
+    return launch_conv<T, 4, 4, 2, 4, 3>(p, st, ws, ws_bytes);                       // 128 x 256, 144 KB LDS
+  }
   switch (tile) {
-    case 192: return launch_conv<T, 6, 4, 2, 2>(p, st, ws, ws_bytes);
-    case 128: return launch_conv<T, 4, 4, 2, 2>(p, st, ws, ws_bytes);
-    default: return launch_conv<T, 4, 4, 1, 4>(p, st, ws, ws_bytes);
+    case 192: return launch_conv<T, 6, 4, 2, 2, 2>(p, st, ws, ws_bytes);
+    case 128: return launch_conv<T, 4, 4, 2, 2, 2>(p, st, ws, ws_bytes);
+    default: return launch_conv<T, 4, 4, 1, 4, 2>(p, st, ws, ws_bytes);
   }
 }
 
