@@ -62,27 +62,40 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
     qf[s] = make_uint4(0, 0, 0, 0);
     if (qrow < p.t) qf[s] = *reinterpret_cast<const uint4*>(base + (size_t)qrow * rowstride + (lg + 4 * s) * 16);
   }
+  // softmax(q.k*scale) == softmax2((q*scale*log2e).k): one multiply per S element saved in the tile loop.  For exact
+  // powers of two (d = 64, 256: scale = 1/8, 1/16) the product q*scale is exact in bf16/f16; log2e is applied in f32 below.
+  const float sc2 = p.scale_log2e;
   f32x4_t o[DT];
 #pragma unroll
   for (int i = 0; i < DT; ++i) o[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
 
   const int ntiles = (p.t + 63) / 64;
+  constexpr int NCH = (64 * CH) / 256;             // 16-byte chunks of K (and of V) staged per thread per tile
+  uint4 pk[NCH], pv[NCH];
+  // register prefetch: the next tile's K/V rows are in flight while the current tile feeds the MFMAs
+#define ATT_LOAD_TILE(key0_)                                                                     \
+  _Pragma("unroll") for (int u = 0; u < NCH; ++u) {                                               \
+    const int idx = tid + 256 * u, r = idx / CH, c = idx - r * CH;                                \
+    pk[u] = make_uint4(0, 0, 0, 0); pv[u] = make_uint4(0, 0, 0, 0);                               \
+    if ((key0_) + r < p.t) {                                                                      \
+      const char* g = base + (size_t)((key0_) + r) * rowstride + c * 16;                          \
+      pk[u] = *reinterpret_cast<const uint4*>(g + (size_t)C * ES);                                \
+      pv[u] = *reinterpret_cast<const uint4*>(g + (size_t)2 * C * ES);                            \
+    }                                                                                             \
+  }
+  ATT_LOAD_TILE(0);
   for (int kt = 0; kt < ntiles; ++kt) {
     const int key0 = kt * 64;
     __syncthreads();                                 // previous tile fully consumed
-    for (int idx = tid; idx < 64 * CH; idx += 256) {
-      const int r = idx / CH, c = idx - r * CH;
-      uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-      if (key0 + r < p.t) {
-        const char* g = base + (size_t)(key0 + r) * rowstride + c * 16;
-        kv = *reinterpret_cast<const uint4*>(g + (size_t)C * ES);
-        vv = *reinterpret_cast<const uint4*>(g + (size_t)2 * C * ES);
-      }
-      *reinterpret_cast<uint4*>(sK + r * ROWB + c * 16) = kv;
-      *reinterpret_cast<uint4*>(sV + r * ROWB + c * 16) = vv;
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const int idx = tid + 256 * u, r = idx / CH, c = idx - r * CH;
+      *reinterpret_cast<uint4*>(sK + r * ROWB + c * 16) = pk[u];
+      *reinterpret_cast<uint4*>(sV + r * ROWB + c * 16) = pv[u];
     }
     __syncthreads();
+    if (kt + 1 < ntiles) { ATT_LOAD_TILE(key0 + 64); }
 
     // ---- S^T tiles: 4 x (16 keys x 16 queries)
     f32x4_t sacc[4];
@@ -95,27 +108,29 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
         sacc[j] = AttMma<T>::run(ka, qf[s], sacc[j]);
       }
     }
-    // ---- online softmax; lane holds keys key0 + j*16 + lg*4 + r of query lq
-    float tmax = -INFINITY;
+    // ---- online softmax; lane holds keys key0 + j*16 + lg*4 + r of query lq.  The running max is kept in the
+    // un-scaled domain and the scale (incl. log2 e) is folded into the exponent: exp2(s*sc2 - m*sc2), one FMA per element.
+    if (key0 + 64 > p.t) {                           // only the last tile of a ragged sequence needs the mask
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = sacc[j][r] * p.scale_log2e;
-        if (key0 + j * 16 + lg * 4 + r >= p.t) v = -INFINITY;
-        sacc[j][r] = v;
-        tmax = fmaxf(tmax, v);
-      }
+        for (int r = 0; r < 4; ++r)
+          if (key0 + j * 16 + lg * 4 + r >= p.t) sacc[j][r] = -INFINITY;
+    }
+    float tmax = fmaxf(fmaxf(sacc[0][0], sacc[0][1]), fmaxf(sacc[0][2], sacc[0][3]));
+#pragma unroll
+    for (int j = 1; j < 4; ++j) tmax = fmaxf(tmax, fmaxf(fmaxf(sacc[j][0], sacc[j][1]), fmaxf(sacc[j][2], sacc[j][3])));
     tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(m_run, tmax);          // finite: every tile has >= 1 valid key
-    const float alpha = exp2f(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc2);
+    const float mb = m_new * sc2;
     float psum = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = exp2f(sacc[j][r] - m_new);
+        const float e = __builtin_amdgcn_exp2f(fmaf(sacc[j][r], sc2, -mb));
         sacc[j][r] = e;
         psum += e;
       }
@@ -123,8 +138,10 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
     psum += __shfl_xor(psum, 32, 64);
     l_run = l_run * alpha + psum;
     m_run = m_new;
+    if (!__all(alpha == 1.0f)) {                     // running max unchanged for the whole wave: nothing to rescale
 #pragma unroll
-    for (int i = 0; i < DT; ++i) o[i] *= alpha;
+      for (int i = 0; i < DT; ++i) o[i] *= alpha;
+    }
 
     // ---- O^T += V^T . P^T ; k-slot (lg, e): e<4 -> key 16*(2kk) + 4lg + e ; e>=4 -> key 16*(2kk+1) + 4lg + e-4
 #pragma unroll

@@ -168,8 +168,8 @@ __global__ void u8_to_unit_kernel(const uint8_t* __restrict__ img, float* __rest
 }
 
 // ---- K7 ------------------------------------------------------------------------------------------------
-// one wave per output column; rows are processed 8 at a time so their loads and reductions overlap
-// (one row at a time was latency-bound: ~2 us of dependent L2 round trip + shuffles per row)
+// one wave per (output column, block of 8 rows): grid.y walks the row blocks so that enough waves are in flight to
+// hide the load latency (a single wave looping over all rows was latency-bound: 200-400 us for a 64x1000x768 problem)
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ y, int ldy, int m, int k,
                                                       int n, int act_in, int act_out, int accumulate) {
@@ -178,33 +178,33 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
   if (col >= n) return;
   const float* wr = w + (size_t)col * k;
   constexpr int RB = 8;
-  for (int row0 = 0; row0 < m; row0 += RB) {
-    float acc[RB];
+  const int row0 = blockIdx.y * RB;
+  float acc[RB];
 #pragma unroll
-    for (int r = 0; r < RB; ++r) acc[r] = 0.f;
-    for (int j = lane; j < k; j += 64) {
-      const float wv = wr[j];
+  for (int r = 0; r < RB; ++r) acc[r] = 0.f;
+#pragma unroll 2
+  for (int j = lane; j < k; j += 64) {
+    const float wv = wr[j];
 #pragma unroll
-      for (int r = 0; r < RB; ++r) {
-        if (row0 + r < m) {
-          float xv = x[(size_t)(row0 + r) * ldx + j];
-          if (act_in) xv = silu_f(xv);
-          acc[r] += xv * wv;
-        }
+    for (int r = 0; r < RB; ++r) {
+      if (row0 + r < m) {
+        float xv = x[(size_t)(row0 + r) * ldx + j];
+        if (act_in) xv = silu_f(xv);
+        acc[r] += xv * wv;
       }
     }
+  }
 #pragma unroll
-    for (int r = 0; r < RB; ++r) acc[r] = wave_sum(acc[r]);
-    if (lane == 0) {
+  for (int r = 0; r < RB; ++r) acc[r] = wave_sum(acc[r]);
+  if (lane == 0) {
 #pragma unroll
-      for (int r = 0; r < RB; ++r) {
-        if (row0 + r < m) {
-          float v = acc[r] + (bias ? bias[col] : 0.f);
-          float* o = y + (size_t)(row0 + r) * ldy + col;
-          if (accumulate) v += *o;
-          if (act_out) v = silu_f(v);
-          *o = v;
-        }
+    for (int r = 0; r < RB; ++r) {
+      if (row0 + r < m) {
+        float v = acc[r] + (bias ? bias[col] : 0.f);
+        float* o = y + (size_t)(row0 + r) * ldy + col;
+        if (accumulate) v += *o;
+        if (act_out) v = silu_f(v);
+        *o = v;
       }
     }
   }
@@ -451,7 +451,7 @@ extern "C" int dts_linear(const float* x, int ldx, const float* w, const float* 
                           int act_out, int accumulate, dts_stream s) {
   DTS_CHECK_ARG(x && w && y && m > 0 && k > 0 && n > 0 && ldx >= k && ldy >= n, "dts_linear: bad args");
   ST;
-  hipLaunchKernelGGL(linear_kernel, dim3((n + 3) / 4), dim3(256), 0, st, x, ldx, w, bias, y, ldy, m, k, n, act_in, act_out, accumulate);
+  hipLaunchKernelGGL(linear_kernel, dim3((n + 3) / 4, (m + 7) / 8), dim3(256), 0, st, x, ldx, w, bias, y, ldy, m, k, n, act_in, act_out, accumulate);
   DTS_CHECK_LAUNCH("dts_linear");
   return DTS_OK;
 }

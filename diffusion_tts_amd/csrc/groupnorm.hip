@@ -141,6 +141,84 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1,
   }
 }
 
+// ---- single-launch GroupNorm for the low-resolution levels (hw <= 256): one block per (group, sample) computes the
+// statistics of its slab (pass 1) and applies x*a+b [+SiLU] (pass 2, served by L1/L2).  Replaces three launches whose
+// cost at these sizes is launch latency, not bytes.  Elements are handled in channel pairs (cg is always even).
+template <typename T> struct Pair;
+template <> struct Pair<float> {
+  static __device__ __forceinline__ void load(const float* p, float& a, float& b) { const float2 v = *reinterpret_cast<const float2*>(p); a = v.x; b = v.y; }
+  static __device__ __forceinline__ void store(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
+};
+template <> struct Pair<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float& a, float& b) {
+    const uint32_t v = *reinterpret_cast<const uint32_t*>(p); a = bf16_bits_to_f32(v & 0xffffu); b = bf16_bits_to_f32(v >> 16);
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, float a, float b) {
+    *reinterpret_cast<uint32_t*>(p) = f32_to_bf16_bits(a) | (f32_to_bf16_bits(b) << 16);
+  }
+};
+template <> struct Pair<f16_t> {
+  static __device__ __forceinline__ void load(const f16_t* p, float& a, float& b) {
+    const uint32_t v = *reinterpret_cast<const uint32_t*>(p); a = f16_bits_to_f32(v & 0xffffu); b = f16_bits_to_f32(v >> 16);
+  }
+  static __device__ __forceinline__ void store(f16_t* p, float a, float b) {
+    *reinterpret_cast<uint32_t*>(p) = f32_to_f16_bits(a) | (f32_to_f16_bits(b) << 16);
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_fused_kernel(const T* __restrict__ x1, int c1, const T* __restrict__ x2, int c2, int hw,
+                                                        int groups, float eps, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const T* __restrict__ ss, int ld_ss,
+                                                        T* __restrict__ out, int silu) {
+  __shared__ double red[2][4];
+  __shared__ float sAB[2][64];                       // per-channel (a, b) of this group (cg <= 64)
+  const int C = c1 + c2, cg = C / groups, hp = cg / 2;
+  const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const int npair = hw * hp;
+  float s = 0.f, q = 0.f;
+  for (int e = tid; e < npair; e += 256) {
+    const int p = e / hp, c = g * cg + (e - p * hp) * 2;
+    const T* src = c < c1 ? x1 + ((size_t)n * hw + p) * c1 + c : x2 + ((size_t)n * hw + p) * c2 + (c - c1);
+    float a, b;
+    Pair<T>::load(src, a, b);
+    s += a + b;
+    q += a * a + b * b;
+  }
+  double ds = wave_sum((double)s), dq = wave_sum((double)q);
+  if ((tid & 63) == 0) { red[0][tid >> 6] = ds; red[1][tid >> 6] = dq; }
+  __syncthreads();
+  if (tid < cg) {
+    const double cnt = (double)hw * cg;
+    const double mean = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / cnt;
+    double var = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const int c = g * cg + tid;
+    float A = rstd * (gamma ? gamma[c] : 1.f);
+    float B = (beta ? beta[c] : 0.f) - (float)mean * A;
+    if (ss) {
+      const float sc = 1.f + ld1<T>(ss + (size_t)n * ld_ss + c);
+      const float sh = ld1<T>(ss + (size_t)n * ld_ss + C + c);
+      A = A * sc;
+      B = B * sc + sh;
+    }
+    sAB[0][tid] = A;
+    sAB[1][tid] = B;
+  }
+  __syncthreads();
+  for (int e = tid; e < npair; e += 256) {
+    const int p = e / hp, cl = (e - p * hp) * 2, c = g * cg + cl;
+    const T* src = c < c1 ? x1 + ((size_t)n * hw + p) * c1 + c : x2 + ((size_t)n * hw + p) * c2 + (c - c1);
+    float a, b;
+    Pair<T>::load(src, a, b);
+    a = a * sAB[0][cl] + sAB[1][cl];
+    b = b * sAB[0][cl + 1] + sAB[1][cl + 1];
+    if (silu) { a = silu_f(a); b = silu_f(b); }
+    Pair<T>::store(out + ((size_t)n * hw + p) * C + c, a, b);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void resample_kernel(const T* __restrict__ x, T* __restrict__ out, int n_total, int h, int w,
                                                         int c, int mode) {
@@ -240,6 +318,26 @@ extern "C" int dts_gn_apply(const void* x1, int c1, const void* x2, int c2, int 
       hipLaunchKernelGGL((gn_apply_kernel<T, false>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x1, c1, (const T*)x2,
                          c2, coef, (T*)out, n, h, w, silu);
     DTS_CHECK_LAUNCH("dts_gn_apply");
+  });
+  return DTS_OK;
+}
+
+extern "C" int dts_gn_fused(const void* x1, int c1, const void* x2, int c2, int dtype, int n, int hw, int groups, float eps,
+                            const float* gamma, const float* beta, const void* scale_shift, int ld_ss, void* out, int silu,
+                            dts_stream s) {
+  const int C = c1 + c2;
+  DTS_CHECK_ARG(x1 && out, "dts_gn_fused: null pointer");
+  DTS_CHECK_ARG(n > 0 && hw > 0 && groups > 0 && C % groups == 0, "dts_gn_fused: C=%d groups=%d", C, groups);
+  const int cg = C / groups;
+  DTS_CHECK_ARG(cg % 2 == 0 && cg <= 64 && c1 % 2 == 0, "dts_gn_fused: channels per group %d unsupported", cg);
+  DTS_CHECK_ARG(c2 == 0 || x2, "dts_gn_fused: c2 without x2");
+  DTS_CHECK_ARG(scale_shift == nullptr || ld_ss >= 2 * C, "dts_gn_fused: ld_ss=%d < 2*C=%d", ld_ss, 2 * C);
+  DTS_CHECK_ARG(n <= 65535, "dts_gn_fused: n too large for grid.y");
+  hipStream_t st = to_stream(s);
+  DTS_DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL((gn_fused_kernel<T>), dim3(groups, n), dim3(256), 0, st, (const T*)x1, c1, (const T*)x2, c2, hw, groups, eps,
+                       gamma, beta, (const T*)scale_shift, ld_ss, (T*)out, silu);
+    DTS_CHECK_LAUNCH("dts_gn_fused");
   });
   return DTS_OK;
 }

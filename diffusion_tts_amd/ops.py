@@ -162,7 +162,25 @@ def gn_apply(x1, coef, *, x2=None, silu=True, pool=False):
     return out
 
 
-def group_norm(x1, groups, eps, gamma, beta, *, x2=None, scale_shift=None, silu=True, pool=False):
+GN_FUSED_MAX_HW = 64        # 8x8 levels take the single-launch kernel (measured: tools/gn_bench.py; larger levels are bandwidth-bound)
+
+
+def group_norm(x1, groups, eps, gamma, beta, *, x2=None, scale_shift=None, silu=True, pool=False, path=None):
+    """GroupNorm [+ (1+scale), shift] [+ SiLU] [+ 2x2 average pool].  path: None = auto, 'fused' | 'split' (tests)."""
+    n, h, w, c1 = x1.shape
+    c2 = 0 if x2 is None else x2.shape[-1]
+    cg = (c1 + c2) // groups
+    fused_ok = (not pool) and cg % 2 == 0 and cg <= 64
+    if path is None:
+        path = 'fused' if (fused_ok and h * w <= GN_FUSED_MAX_HW) else 'split'
+    if path == 'fused':
+        if not fused_ok:
+            raise ValueError('fused GroupNorm needs pool=False and an even number (<= 64) of channels per group')
+        out = torch.empty((n, h, w, c1 + c2), dtype=x1.dtype, device=x1.device)
+        ss_ptr, ss_ld = _rows(scale_shift, 'scale_shift', x1.dtype)
+        _call('dts_gn_fused', _ptr(x1, 'x1'), c1, _ptr(x2, 'x2', x1.dtype), c2, dt_code(x1.dtype), n, h * w, groups, float(eps),
+              _ptr(gamma, 'gamma', torch.float32), _ptr(beta, 'beta', torch.float32), ss_ptr, ss_ld, _ptr(out), int(silu))
+        return out
     return gn_apply(x1, gn_coef(x1, groups, eps, gamma, beta, x2=x2, scale_shift=scale_shift), x2=x2, silu=silu, pool=pool)
 
 

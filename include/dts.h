@@ -84,6 +84,10 @@ int dts_gn_coef(const void* x1, int c1, const void* x2, int c2, int dtype, int n
  * networks.py:84-85; unet.py:213-215 avg_pool) and writes [n][h/2][w/2][C]. */
 int dts_gn_apply(const void* x1, int c1, const void* x2, int c2, int dtype, const float* coef,
                  void* out, int n, int h, int w, int silu, int pool, dts_stream s);
+/* single-launch variant for low-resolution levels (hw <= ~256): statistics + apply in one kernel, one block per
+ * (group, sample); same result as dts_gn_coef + dts_gn_apply(pool=0).  Channels per group must be even and <= 64. */
+int dts_gn_fused(const void* x1, int c1, const void* x2, int c2, int dtype, int n, int hw, int groups, float eps,
+                 const float* gamma, const float* beta, const void* scale_shift, int ld_ss, void* out, int silu, dts_stream s);
 /* 2x resampling of an NHWC tensor for the skip path: mode 0 = 2x2 average (down), 1 = nearest (up). */
 int dts_resample2x(const void* x, void* out, int dtype, int n, int h, int w, int c, int mode, dts_stream s);
 

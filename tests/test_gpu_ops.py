@@ -133,8 +133,11 @@ def test_conv_in3_out3(ops, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('path', ['fused', 'split'])
 @pytest.mark.parametrize('variant', ['plain', 'adaptive', 'pool', 'cat', 'nosilu'])
-def test_group_norm(ops, dtype, variant):
+def test_group_norm(ops, dtype, variant, path):
+    if variant == 'pool' and path == 'fused':
+        pytest.skip('pooled GroupNorm always takes the split path')
     gen = g(4)
     n, c, h, w = 3, 192, 8, 8
     x = q(torch.randn(n, c, h, w, generator=gen) * 2 + 0.5, dtype)
@@ -156,7 +159,8 @@ def test_group_norm(ops, dtype, variant):
         x1, x2 = to_nhwc(ops, x[:, :128], dtype), to_nhwc(ops, x[:, 128:], dtype)
     else:
         x1, x2 = to_nhwc(ops, x, dtype), None
-    out = ops.group_norm(x1, groups, 1e-5, gamma.to(DEV), beta.to(DEV), x2=x2, scale_shift=ss, silu=silu, pool=variant == 'pool')
+    out = ops.group_norm(x1, groups, 1e-5, gamma.to(DEV), beta.to(DEV), x2=x2, scale_shift=ss, silu=silu, pool=variant == 'pool',
+                         path=path)
     got = from_nhwc(ops, out)
     assert rel_err(got, ref) < (1e-5 if dtype == torch.float32 else TOL[dtype])
 
@@ -168,8 +172,9 @@ def test_group_norm_many_pixels_and_wide(ops, dtype):
         x = q(torch.randn(n, c, h, h, generator=gen) + 1.0, dtype)
         gamma, beta = torch.randn(c, generator=gen), torch.randn(c, generator=gen)
         ref = onet.silu(onet.group_norm(x, gamma, beta, 1e-6))
-        out = ops.group_norm(to_nhwc(ops, x, dtype), min(32, c // 4), 1e-6, gamma.to(DEV), beta.to(DEV))
-        assert rel_err(from_nhwc(ops, out), ref) < (2e-5 if dtype == torch.float32 else TOL[dtype])
+        for path in ('split', 'fused'):
+            out = ops.group_norm(to_nhwc(ops, x, dtype), min(32, c // 4), 1e-6, gamma.to(DEV), beta.to(DEV), path=path)
+            assert rel_err(from_nhwc(ops, out), ref) < (2e-5 if dtype == torch.float32 else TOL[dtype]), path
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
