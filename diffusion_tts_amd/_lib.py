@@ -21,7 +21,7 @@ class ConvArgs(C.Structure):
                 ('bias_nc', _p), ('ld_bias_nc', C.c_int32), ('residual', _p), ('out', _p),
                 ('n', C.c_int32), ('hin', C.c_int32), ('win', C.c_int32), ('cout', C.c_int32),
                 ('ksize', C.c_int32), ('up', C.c_int32), ('out_scale', C.c_float), ('dtype', C.c_int32),
-                ('workspace', _p), ('workspace_bytes', C.c_int64)]
+                ('workspace', _p), ('workspace_bytes', C.c_int64), ('stats_out', _p), ('stats_written', C.c_int32)]
 
 
 # name -> argtypes (every function returns int status except the three noted below)
@@ -33,6 +33,7 @@ SIGNATURES = {
     'dts_conv_in3': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     'dts_conv_out3': [_p, _i, _p, _p, _p, _i, _i, _i, _i, _p],
     'dts_gn_coef': [_p, _i, _p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _i, _p, _p, _p],
+    'dts_gn_coef_strips': [_p, _i, _p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _i, _p, _p],
     'dts_gn_apply': [_p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p],
     'dts_gn_fused': [_p, _i, _p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _i, _p, _i, _p],
     'dts_resample2x': [_p, _p, _i, _i, _i, _i, _i, _i, _p],

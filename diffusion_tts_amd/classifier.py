@@ -85,11 +85,11 @@ class EncoderUNetModel:
         h = ops.group_norm(x, 32, 1e-5, P.g0, P.b0, silu=True, pool=L.down)
         if L.down:
             x = ops.resample2x(x, up=False)
-        h = ops.conv2d(h, P.w0, P.cb0)
+        h = ops.conv2d(h, P.w0, P.cb0, gn_stats=True)
         ss = emb_all[:, P.off:P.off + 2 * L.cout]
         h = ops.group_norm(h, 32, 1e-5, P.g1, P.b1, scale_shift=ss, silu=True)
         sk = x if P.sw is None else ops.conv2d(x, P.sw, P.sb)
-        return ops.conv2d(h, P.w1, P.cb1, residual=sk)
+        return ops.conv2d(h, P.w1, P.cb1, residual=sk, gn_stats=True)
 
     def _attn(self, L: ClsLayer, x):
         P = self.params[L.prefix]
@@ -97,7 +97,7 @@ class EncoderUNetModel:
         hn = ops.group_norm(x, 32, 1e-5, P.g, P.b, silu=False)
         qkv = ops.conv2d(hn, P.wqkv, P.bqkv)
         a = ops.attention(qkv.view(n, hh * ww, 3 * c), P.heads, 1.0 / math.sqrt(c // P.heads))
-        return ops.conv2d(a.view(n, hh, ww, c), P.wproj, P.bproj, residual=x)
+        return ops.conv2d(a.view(n, hh, ww, c), P.wproj, P.bproj, residual=x, gn_stats=True)
 
     @torch.no_grad()
     def __call__(self, x, timesteps):

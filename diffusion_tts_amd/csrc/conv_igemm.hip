@@ -24,6 +24,8 @@
 
 namespace {
 
+thread_local bool g_stats_written = false;
+
 struct ConvP {
   const char* x1; const char* x2;
   const char* w;
@@ -42,6 +44,7 @@ struct ConvP {
   int splits;      // split-K factor (grid.y); > 1 => f32 partial slabs + dts reduce kernel
   int ks_per_split;
   float* partial;  // [splits][P][cout] f32 when splits > 1
+  float* stats;    // optional [ceil(P/64)][cout][2]: per 64-pixel strip (sum, sumsq) of the stored outputs (GroupNorm input)
   float out_scale;
 };
 
@@ -71,6 +74,7 @@ template <typename T> struct Vec4;
 template <> struct Vec4<float> {
   using type = float4;
   static __device__ __forceinline__ void unpack(const float4& v, float* f) { f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
+  static __device__ __forceinline__ float4 pack(const float* f) { return make_float4(f[0], f[1], f[2], f[3]); }
   static __device__ __forceinline__ void load(const float* p, float* f) {
     const float4 v = *reinterpret_cast<const float4*>(p);
     f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
@@ -81,6 +85,9 @@ template <> struct Vec4<float> {
 };
 template <> struct Vec4<bf16_t> {
   using type = uint2;
+  static __device__ __forceinline__ uint2 pack(const float* f) {
+    return make_uint2(f32_to_bf16_bits(f[0]) | (f32_to_bf16_bits(f[1]) << 16), f32_to_bf16_bits(f[2]) | (f32_to_bf16_bits(f[3]) << 16));
+  }
   static __device__ __forceinline__ void unpack(const uint2& v, float* f) {
     f[0] = bf16_bits_to_f32(v.x & 0xffffu); f[1] = bf16_bits_to_f32(v.x >> 16);
     f[2] = bf16_bits_to_f32(v.y & 0xffffu); f[3] = bf16_bits_to_f32(v.y >> 16);
@@ -97,6 +104,9 @@ template <> struct Vec4<bf16_t> {
 };
 template <> struct Vec4<f16_t> {
   using type = uint2;
+  static __device__ __forceinline__ uint2 pack(const float* f) {
+    return make_uint2(f32_to_f16_bits(f[0]) | (f32_to_f16_bits(f[1]) << 16), f32_to_f16_bits(f[2]) | (f32_to_f16_bits(f[3]) << 16));
+  }
   static __device__ __forceinline__ void unpack(const uint2& v, float* f) {
     f[0] = f16_bits_to_f32(v.x & 0xffffu); f[1] = f16_bits_to_f32(v.x >> 16);
     f[2] = f16_bits_to_f32(v.y & 0xffffu); f[3] = f16_bits_to_f32(v.y >> 16);
@@ -295,59 +305,87 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_ige
     }
     return;
   }
-  // All global reads of the epilogue are issued before the first store: `out` may alias nothing here, but the
-  // compiler cannot know that, and interleaved load/store pairs would serialise 24 memory round trips per lane.
+  // Epilogue, one 16-cout slice (mt) at a time.  The residual / per-sample-bias reads of slice mt+1 are issued before
+  // the stores of slice mt (software prefetch): interleaved load->store pairs would serialise a memory round trip per
+  // (mt, nt) because the compiler must assume `out` aliases the inputs; holding all MT*NT vectors live at once (the
+  // previous version) pushed the 192x128 tile to 256 VGPRs and into scratch once the statistics were added.
   const T* __restrict__ res = reinterpret_cast<const T*>(kp.residual);
   const T* __restrict__ bnc = reinterpret_cast<const T*>(kp.bias_nc);
   T* __restrict__ out = reinterpret_cast<T*>(kp.out);
   const int hw = p_hout * p_wout;
   using V4 = typename Vec4<T>::type;
-  float4 bv[MT];
+  int ppv[NT], nsv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int pp = pn0 + wn * 16 * NT + nt * 16 + lrow;
+    ppv[nt] = pp < p_P ? pp : -1;
+    nsv[nt] = pp < p_P ? pp / hw : 0;
+  }
+  V4 rv[2][NT], nv[2][NT];
+  float4 bcur;
+#define EPI_LOAD(slot_, mt_)                                                                              \
+  {                                                                                                       \
+    const int co_ = cm0 + wm * 16 * MT + (mt_) * 16 + lq * 4;                                             \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                   \
+      if (res && ppv[nt] >= 0) rv[slot_][nt] = *reinterpret_cast<const V4*>(res + (size_t)ppv[nt] * p_cout + co_); \
+      if (bnc && ppv[nt] >= 0) nv[slot_][nt] = *reinterpret_cast<const V4*>(bnc + (size_t)nsv[nt] * kp.ld_bias_nc + co_); \
+    }                                                                                                     \
+  }
+  EPI_LOAD(0, 0);
+  const bool want_stats = NT == 4 && kp.stats != nullptr;
+  float* sp = want_stats ? kp.stats + ((size_t)((pn0 + wn * 64) >> 6) * p_cout) * 2 : nullptr;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
+    const int slot = mt & 1;
     const int co = cm0 + wm * 16 * MT + mt * 16 + lq * 4;
-    bv[mt] = kp.bias ? *reinterpret_cast<const float4*>(kp.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  V4 rv[MT][NT], nv[MT][NT];
+    bcur = kp.bias ? *reinterpret_cast<const float4*>(kp.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mt + 1 < MT) { EPI_LOAD(slot ^ 1, mt + 1); }
+    float ss4[4] = {0.f, 0.f, 0.f, 0.f}, sq4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int pp = pn0 + wn * 16 * NT + nt * 16 + lrow;
-    const bool ok = pp < p_P;
-    const int n = ok ? pp / hw : 0;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int co = cm0 + wm * 16 * MT + mt * 16 + lq * 4;
-      if (res && ok) rv[mt][nt] = *reinterpret_cast<const V4*>(res + (size_t)pp * p_cout + co);
-      if (bnc && ok) nv[mt][nt] = *reinterpret_cast<const V4*>(bnc + (size_t)n * kp.ld_bias_nc + co);
-    }
-  }
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int pp = pn0 + wn * 16 * NT + nt * 16 + lrow;
-    if (pp >= p_P) continue;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int co = cm0 + wm * 16 * MT + mt * 16 + lq * 4;
+    for (int nt = 0; nt < NT; ++nt) {
+      if (ppv[nt] < 0) continue;
       float v[4];
-      v[0] = acc[mt][nt][0] + bv[mt].x; v[1] = acc[mt][nt][1] + bv[mt].y;
-      v[2] = acc[mt][nt][2] + bv[mt].z; v[3] = acc[mt][nt][3] + bv[mt].w;
+      v[0] = acc[mt][nt][0] + bcur.x; v[1] = acc[mt][nt][1] + bcur.y;
+      v[2] = acc[mt][nt][2] + bcur.z; v[3] = acc[mt][nt][3] + bcur.w;
       if (bnc) {
         float f[4];
-        Vec4<T>::unpack(nv[mt][nt], f);
+        Vec4<T>::unpack(nv[slot][nt], f);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += f[r];
       }
       if (res) {
         float f[4];
-        Vec4<T>::unpack(rv[mt][nt], f);
+        Vec4<T>::unpack(rv[slot][nt], f);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += f[r];
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] *= kp.out_scale;
-      Vec4<T>::store(out + (size_t)pp * p_cout + co, v);
+      const V4 pk = Vec4<T>::pack(v);
+      *reinterpret_cast<V4*>(out + (size_t)ppv[nt] * p_cout + co) = pk;
+      if (want_stats) {                                // moments of the values as stored (rounded to T)
+        float f[4];
+        Vec4<T>::unpack(pk, f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ss4[r] += f[r]; sq4[r] += f[r] * f[r]; }
+      }
+    }
+    if (want_stats) {
+      // Fused GroupNorm statistics (input moments of the next networks.py:104-106 norm): this wave covers one 64-pixel
+      // strip; fixed-order reduction over the 16 pixel lanes, (sum, sumsq) per (strip, cout).  No atomics.
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { ss4[r] += __shfl_xor(ss4[r], o, 64); sq4[r] += __shfl_xor(sq4[r], o, 64); }
+      }
+      if (lrow == 0 && pn0 + wn * 64 < p_P) {
+        float4* d = reinterpret_cast<float4*>(sp + (size_t)co * 2);
+        d[0] = make_float4(ss4[0], sq4[0], ss4[1], sq4[1]);
+        d[1] = make_float4(ss4[2], sq4[2], ss4[3], sq4[3]);
+      }
     }
   }
+#undef EPI_LOAD
 }
 
 // split-K second pass: fixed-order sum of the f32 slabs + the conv epilogue
@@ -408,6 +446,8 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes) {
   splits = (nk + q.ks_per_split - 1) / q.ks_per_split;       // no empty split
   q.splits = splits;
   q.partial = ws;
+  if (splits > 1 || NT != 4) q.stats = nullptr;              // the split-K reduce pass does not produce statistics
+  g_stats_written = q.stats != nullptr;
   const size_t lds = (size_t)STAGES * (BM + BN) * 128;
   static bool attr_done = false;
   if (!attr_done) {
@@ -476,8 +516,14 @@ extern "C" int dts_conv2d(const dts_conv_args* a, dts_stream s) {
   DTS_CHECK_ARG(P < (1ll << 30), "dts_conv2d: too many pixels");
   p.P = (int)P; p.out_scale = a->out_scale; p.n_ct = p.n_pt = 0;
   p.splits = 1; p.ks_per_split = 0; p.partial = nullptr;
+  p.stats = a->stats_out;
+  DTS_CHECK_ARG(a->stats_out == nullptr || ((p.hout * p.wout) % 64 == 0 && (uintptr_t)a->stats_out % 16 == 0),
+                "dts_conv2d: strip statistics need hout*wout to be a multiple of 64 and a 16-byte aligned buffer");
   DTS_CHECK_ARG(a->workspace == nullptr || ((uintptr_t)a->workspace % 16 == 0 && a->workspace_bytes >= 0), "dts_conv2d: workspace");
   hipStream_t st = to_stream(s);
-  DTS_DISPATCH_DTYPE(a->dtype, return conv_dispatch<T>(p, st, (float*)a->workspace, (long long)a->workspace_bytes));
-  return DTS_OK;
+  int rc = DTS_OK;
+  g_stats_written = false;
+  DTS_DISPATCH_DTYPE(a->dtype, rc = conv_dispatch<T>(p, st, (float*)a->workspace, (long long)a->workspace_bytes));
+  const_cast<dts_conv_args*>(a)->stats_written = g_stats_written ? 1 : 0;
+  return rc;
 }

@@ -93,6 +93,47 @@ __global__ void gn_coef_kernel(const float* __restrict__ partial, int splits, in
   coef[(size_t)idx * 2 + 1] = B;
 }
 
+// coefficients from the per-64-pixel-strip statistics the producing convolutions emitted (conv_igemm.hip epilogue).
+// One wave per (group, sample): lane-strided sum over the group's strips x channels, fixed-order f64 wave reduction,
+// then the group's channels get their (a, b).
+template <typename T>
+__global__ __launch_bounds__(64) void gn_coef_strips_kernel(const float* __restrict__ st1, int c1, const float* __restrict__ st2,
+                                                             int c2, int strips, int groups, int hw, float eps,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const T* __restrict__ ss, int ld_ss, float* __restrict__ coef) {
+  const int C = c1 + c2, cg = C / groups, g = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
+  double a = 0.0, b = 0.0;
+  const int total = strips * cg;
+  for (int e = lane; e < total; e += 64) {
+    const int s = e / cg, c = g * cg + (e - s * cg);
+    const float* src; int cs, co;
+    if (c < c1) { src = st1; cs = c1; co = c; } else { src = st2; cs = c2; co = c - c1; }
+    const float2 q = *reinterpret_cast<const float2*>(src + (((size_t)n * strips + s) * cs + co) * 2);
+    a += q.x; b += q.y;
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const double cnt = (double)hw * cg;
+  const double mean = a / cnt;
+  double var = b / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float fm = (float)mean;
+  for (int ch = lane; ch < cg; ch += 64) {
+    const int c = g * cg + ch;
+    float A = rstd * (gamma ? gamma[c] : 1.f);
+    float B = (beta ? beta[c] : 0.f) - fm * A;
+    if (ss) {
+      const float sc = 1.f + ld1<T>(ss + (size_t)n * ld_ss + c);
+      const float sh = ld1<T>(ss + (size_t)n * ld_ss + C + c);
+      A = A * sc;
+      B = B * sc + sh;
+    }
+    coef[((size_t)n * C + c) * 2 + 0] = A;
+    coef[((size_t)n * C + c) * 2 + 1] = B;
+  }
+}
+
 template <typename T, bool POOL>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1, int c1, const T* __restrict__ x2, int c2,
                                                         const float* __restrict__ coef, T* __restrict__ out,
@@ -296,6 +337,25 @@ extern "C" int dts_gn_coef(const void* x1, int c1, const void* x2, int c2, int d
     hipLaunchKernelGGL((gn_coef_kernel<T>), dim3((total + 255) / 256), dim3(256), 0, st, ws, splits, groups, C, hw, eps, gamma,
                        beta, (const T*)scale_shift, ld_ss, coef, n);
     DTS_CHECK_LAUNCH("dts_gn_coef(coef)");
+  });
+  return DTS_OK;
+}
+
+extern "C" int dts_gn_coef_strips(const float* st1, int c1, const float* st2, int c2, int dtype, int n, int hw, int groups, float eps,
+                                  const float* gamma, const float* beta, const void* scale_shift, int ld_ss, float* coef,
+                                  dts_stream s) {
+  const int C = c1 + c2;
+  DTS_CHECK_ARG(st1 && coef, "dts_gn_coef_strips: null pointer");
+  DTS_CHECK_ARG(n > 0 && hw > 0 && hw % 64 == 0 && groups > 0 && C % groups == 0, "dts_gn_coef_strips: hw=%d C=%d groups=%d", hw, C,
+                groups);
+  DTS_CHECK_ARG(c2 == 0 || st2, "dts_gn_coef_strips: c2 without st2");
+  DTS_CHECK_ARG(scale_shift == nullptr || ld_ss >= 2 * C, "dts_gn_coef_strips: ld_ss=%d < 2*C=%d", ld_ss, 2 * C);
+  DTS_CHECK_ARG(n <= 65535, "dts_gn_coef_strips: n too large for grid.y");
+  hipStream_t st = to_stream(s);
+  DTS_DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL((gn_coef_strips_kernel<T>), dim3(groups, n), dim3(64), 0, st, st1, c1, st2, c2, hw / 64, groups, hw, eps,
+                       gamma, beta, (const T*)scale_shift, ld_ss, coef);
+    DTS_CHECK_LAUNCH("dts_gn_coef_strips");
   });
   return DTS_OK;
 }

@@ -164,7 +164,7 @@ class EDMPrecond:
         G = self._groups
         ss = aff[:, P.aff_off:P.aff_off + P.caff]
         h = ops.group_norm(x1, G(b.cin), self.eps, P.g0, P.b0, x2=x2, silu=True, pool=b.down)
-        h = ops.conv2d(h, P.w0, P.cb0, up=b.up, bias_nc=None if self.adm else ss)
+        h = ops.conv2d(h, P.w0, P.cb0, up=b.up, bias_nc=None if self.adm else ss, gn_stats=True)
         h = ops.group_norm(h, G(b.cout), self.eps, P.g1, P.b1, scale_shift=ss if self.adm else None, silu=True)
         if P.skip_w is not None:
             src1, src2 = (ops.resample2x(x1, up=False), None) if b.down else (x1, x2)
@@ -173,13 +173,13 @@ class EDMPrecond:
             sk = ops.resample2x(x1, up=b.up)
         else:
             sk = x1
-        x = ops.conv2d(h, P.w1, P.cb1, residual=sk, out_scale=self.skip_scale)
+        x = ops.conv2d(h, P.w1, P.cb1, residual=sk, out_scale=self.skip_scale, gn_stats=True)
         if b.heads:
             n, hh, ww, c = x.shape
             hn = ops.group_norm(x, G(c), self.eps, P.g2, P.b2, silu=False)
             qkv = ops.conv2d(hn, P.wqkv, P.bqkv)
             a = ops.attention(qkv.view(n, hh * ww, 3 * c), b.heads, 1.0 / math.sqrt(c // b.heads))
-            x = ops.conv2d(a.view(n, hh, ww, c), P.wproj, P.bproj, residual=x, out_scale=self.skip_scale)
+            x = ops.conv2d(a.view(n, hh, ww, c), P.wproj, P.bproj, residual=x, out_scale=self.skip_scale, gn_stats=True)
         return x
 
     @torch.no_grad()

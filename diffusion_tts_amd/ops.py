@@ -92,7 +92,10 @@ def _conv_workspace(device):
     return ws
 
 
-def conv2d(x1, w, bias=None, *, x2=None, bias_nc=None, residual=None, up=False, out_scale=1.0, out=None):
+def conv2d(x1, w, bias=None, *, x2=None, bias_nc=None, residual=None, up=False, out_scale=1.0, out=None, gn_stats=False):
+    """gn_stats=True: the epilogue also emits the GroupNorm moments of the output (per 64-pixel strip and channel); they
+    ride on the returned tensor as `out._gn_stats` (None when the launch could not produce them) and are consumed by
+    group_norm(), which then skips its own pass over the tensor."""
     n, hin, win, c1 = x1.shape
     c2 = 0 if x2 is None else x2.shape[-1]
     cout, kh, kw, cin = w.shape
@@ -115,7 +118,12 @@ def conv2d(x1, w, bias=None, *, x2=None, bias_nc=None, residual=None, up=False, 
     a.up, a.out_scale, a.dtype = int(up), float(out_scale), dt_code(x1.dtype)
     ws = _conv_workspace(x1.device)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    st = None
+    if gn_stats and (ho * wo) % 64 == 0:
+        st = torch.empty(((n * ho * wo) // 64, cout, 2), dtype=torch.float32, device=x1.device)
+        a.stats_out = st.data_ptr()
     _call('dts_conv2d', C.byref(a))
+    out._gn_stats = st if (st is not None and a.stats_written) else None
     return out
 
 
@@ -171,6 +179,17 @@ def group_norm(x1, groups, eps, gamma, beta, *, x2=None, scale_shift=None, silu=
     c2 = 0 if x2 is None else x2.shape[-1]
     cg = (c1 + c2) // groups
     fused_ok = (not pool) and cg % 2 == 0 and cg <= 64
+    st1 = getattr(x1, '_gn_stats', None)
+    st2 = None if x2 is None else getattr(x2, '_gn_stats', None)
+    if path in (None, 'strips') and st1 is not None and (x2 is None or st2 is not None) and (h * w) % 64 == 0:
+        coef = torch.empty((n, c1 + c2, 2), dtype=torch.float32, device=x1.device)
+        ss_ptr, ss_ld = _rows(scale_shift, 'scale_shift', x1.dtype)
+        _call('dts_gn_coef_strips', _ptr(st1, 'st1', torch.float32), c1, _ptr(st2, 'st2', torch.float32), c2, dt_code(x1.dtype), n,
+              h * w, groups, float(eps), _ptr(gamma, 'gamma', torch.float32), _ptr(beta, 'beta', torch.float32), ss_ptr, ss_ld,
+              _ptr(coef))
+        return gn_apply(x1, coef, x2=x2, silu=silu, pool=pool)
+    if path == 'strips':
+        raise ValueError('strip statistics are not attached to the input(s)')
     if path is None:
         path = 'fused' if (fused_ok and h * w <= GN_FUSED_MAX_HW) else 'split'
     if path == 'fused':

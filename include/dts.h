@@ -61,6 +61,9 @@ typedef struct dts_conv_args {
   int32_t dtype;
   void* workspace;                /* optional scratch (16-byte aligned) for split-K partial sums; NULL disables split-K */
   int64_t workspace_bytes;
+  float* stats_out;               /* optional [ceil(P/64)][cout][2] f32: per 64-pixel strip (sum, sumsq) of the stored outputs,
+                                     the GroupNorm moments of the NEXT layer fused into this epilogue (needs hout*wout % 64 == 0) */
+  int32_t stats_written;          /* OUT: 1 if stats_out was filled (0 when the launch took the split-K path: fall back to dts_gn_coef) */
 } dts_conv_args;
 int dts_conv2d(const dts_conv_args* a, dts_stream s);
 
@@ -80,6 +83,10 @@ int64_t dts_gn_ws_floats(int n, int groups);
 int dts_gn_coef(const void* x1, int c1, const void* x2, int c2, int dtype, int n, int hw, int groups, float eps,
                 const float* gamma, const float* beta, const void* scale_shift, int ld_ss,
                 float* coef, float* ws, dts_stream s);
+/* same coefficients from strip statistics emitted by dts_conv2d (stats_out) for each source: st1 [n*hw/64][c1][2],
+ * st2 [n*hw/64][c2][2] (NULL when c2 == 0); no pass over x at all. */
+int dts_gn_coef_strips(const float* st1, int c1, const float* st2, int c2, int dtype, int n, int hw, int groups, float eps,
+                       const float* gamma, const float* beta, const void* scale_shift, int ld_ss, float* coef, dts_stream s);
 /* out = act(x*a + b); pool=1 averages 2x2 pixel blocks after the activation (resample filter [1,1],
  * networks.py:84-85; unet.py:213-215 avg_pool) and writes [n][h/2][w/2][C]. */
 int dts_gn_apply(const void* x1, int c1, const void* x2, int c2, int dtype, const float* coef,

@@ -106,6 +106,35 @@ def test_conv2d_big_tiles(ops, dtype):
     assert rel_err(from_nhwc(ops, out), ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_conv_epilogue_emits_group_norm_statistics(ops, dtype):
+    """the GroupNorm moments fused into the conv epilogue give the same normalisation as the standalone pass,
+    for single and concatenated sources, and are withheld (None) when the launch takes the split-K path."""
+    gen = g(21)
+    n, h, w, c, cout = 2, 16, 16, 64, 128
+    x = q(torch.randn(n, c, h, w, generator=gen), dtype)
+    wt = q(torch.randn(cout, c, 1, 1, generator=gen) / 8, dtype)        # 1x1: few K-steps, so no split-K in any dtype
+    wt2 = q(torch.randn(64, c, 1, 1, generator=gen) / 8, dtype)
+    bias = torch.randn(cout, generator=gen)
+    xd = to_nhwc(ops, x, dtype)
+    y1 = ops.conv2d(xd, ops.pack_conv_weight(wt.to(DEV), dtype), bias.to(DEV), gn_stats=True)
+    y2 = ops.conv2d(xd, ops.pack_conv_weight(wt2.to(DEV), dtype), None, gn_stats=True)
+    assert y1._gn_stats is not None and y2._gn_stats is not None
+    ctot = cout + 64
+    gamma, beta = torch.randn(ctot, generator=gen), torch.randn(ctot, generator=gen)
+    a = ops.group_norm(y1, 32, 1e-5, gamma.to(DEV), beta.to(DEV), x2=y2, path='strips')
+    y1._gn_stats = y2._gn_stats = None
+    b = ops.group_norm(y1, 32, 1e-5, gamma.to(DEV), beta.to(DEV), x2=y2, path='split')
+    assert rel_err(a.float().cpu(), b.float().cpu()) < (1e-5 if dtype == torch.float32 else 2e-2)
+    ref = onet.silu(onet.group_norm(torch.cat([from_nhwc(ops, y1), from_nhwc(ops, y2)], 1), gamma, beta, 1e-5))
+    assert rel_err(from_nhwc(ops, a), ref) < (2e-5 if dtype == torch.float32 else TOL[dtype])
+    # split-K launch (1 tile, long K): statistics are not produced and the caller falls back
+    xs = q(torch.randn(1, 256, 8, 8, generator=gen), dtype)
+    ws = q(torch.randn(128, 256, 3, 3, generator=gen) / 48, dtype)
+    ys = ops.conv2d(to_nhwc(ops, xs, dtype), ops.pack_conv_weight(ws.to(DEV), dtype), None, gn_stats=True)
+    assert ys._gn_stats is None
+
+
 def test_conv2d_identical_rows_are_bit_identical(ops):
     """ties must stay ties: the same candidate at different batch positions gives the same bits."""
     gen = g(2)
