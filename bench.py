@@ -88,7 +88,7 @@ def parse():
     ap.add_argument('--scorer', default='imagenet', choices=['imagenet', 'brightness'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=8, help='candidates in the CPU-baseline sample')
+    ap.add_argument('--cpu-sample', type=int, default=32, help='candidates in the CPU-baseline sample')
     return ap.parse_args()
 
 

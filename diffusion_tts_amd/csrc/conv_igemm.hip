@@ -258,26 +258,37 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_ige
   const int lrow = lane & 15, lq = lane >> 4;
   int buf = 0;
   for (int ks = ks_begin; ks < ks_end; ++ks) {
+    const char* sa = smem + buf * STAGE_BYTES + (wm * 16 * MT) * 128;
+    const char* sb = smem + buf * STAGE_BYTES + A_BYTES + (wn * 16 * NT) * 128;
+    uint4 fa[MT], fb[NT];
+    // fragment reads of the first k-substep go out first; the LDS-DMA issue for the tile STAGES-1 ahead (address
+    // arithmetic + M0 writes, ~400 issue cycles) then overlaps their latency instead of delaying the first MFMA
+#pragma unroll
+    for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq));
+#pragma unroll
+    for (int i = 0; i < NT; ++i) fb[i] = *reinterpret_cast<const uint4*>(sb + swz(i * 16 + lrow, lq));
     // the buffer written here was last read in iteration ks-1; every wave has passed that iteration's barrier
     if (ks + STAGES - 1 < ks_end) {
       ADVANCE_K();
       const int wb = buf + STAGES - 1 >= STAGES ? buf - 1 : buf + STAGES - 1;
       ISSUE_TILE(wb, ks + STAGES - 1, ci0);
     }
-    const char* sa = smem + buf * STAGE_BYTES + (wm * 16 * MT) * 128;
-    const char* sb = smem + buf * STAGE_BYTES + A_BYTES + (wn * 16 * NT) * 128;
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      uint4 fa[MT], fb[NT];
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq + 4 * s));
+      for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
+    __builtin_amdgcn_s_setprio(0);
 #pragma unroll
-      for (int i = 0; i < NT; ++i) fb[i] = *reinterpret_cast<const uint4*>(sb + swz(i * 16 + lrow, lq + 4 * s));
+    for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq + 4));
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < NT; ++i) fb[i] = *reinterpret_cast<const uint4*>(sb + swz(i * 16 + lrow, lq + 4));
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
-    }
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
+    __builtin_amdgcn_s_setprio(0);
     // next tile has landed (LDS-DMA completion is tracked by vmcnt; with 3 stages the tile after it stays in
     // flight across the barrier) and this wave's LDS reads of the current tile have returned
     if (STAGES == 3 && ks + 2 < ks_end) {
@@ -305,10 +316,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_ige
     }
     return;
   }
-  // Epilogue, one 16-cout slice (mt) at a time.  The residual / per-sample-bias reads of slice mt+1 are issued before
-  // the stores of slice mt (software prefetch): interleaved load->store pairs would serialise a memory round trip per
-  // (mt, nt) because the compiler must assume `out` aliases the inputs; holding all MT*NT vectors live at once (the
-  // previous version) pushed the 192x128 tile to 256 VGPRs and into scratch once the statistics were added.
+  // Epilogue, one 16-cout slice (mt) at a time; interleaved load->store pairs would serialise a memory round trip per
+  // (mt, nt) because the compiler must assume `out` aliases the inputs, so the reads are hoisted by hand.
   const T* __restrict__ res = reinterpret_cast<const T*>(kp.residual);
   const T* __restrict__ bnc = reinterpret_cast<const T*>(kp.bias_nc);
   T* __restrict__ out = reinterpret_cast<T*>(kp.out);
@@ -321,25 +330,33 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_ige
     ppv[nt] = pp < p_P ? pp : -1;
     nsv[nt] = pp < p_P ? pp / hw : 0;
   }
-  V4 rv[2][NT], nv[2][NT];
-  float4 bcur;
-#define EPI_LOAD(slot_, mt_)                                                                              \
-  {                                                                                                       \
-    const int co_ = cm0 + wm * 16 * MT + (mt_) * 16 + lq * 4;                                             \
-    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                                   \
-      if (res && ppv[nt] >= 0) rv[slot_][nt] = *reinterpret_cast<const V4*>(res + (size_t)ppv[nt] * p_cout + co_); \
-      if (bnc && ppv[nt] >= 0) nv[slot_][nt] = *reinterpret_cast<const V4*>(bnc + (size_t)nsv[nt] * kp.ld_bias_nc + co_); \
-    }                                                                                                     \
+  // residual vectors: all MT*NT reads in flight before the first store (a memory round trip per slice otherwise);
+  // the rarer per-sample bias (SongUNet's conv0) is fetched per slice to keep the register budget under 256.
+  V4 rv[MT][NT], nv[NT];
+  float4 bv[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+    bv[mt] = kp.bias ? *reinterpret_cast<const float4*>(kp.bias + cm0 + wm * 16 * MT + mt * 16 + lq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  if (res) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int co_ = cm0 + wm * 16 * MT + mt * 16 + lq * 4;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        if (ppv[nt] >= 0) rv[mt][nt] = *reinterpret_cast<const V4*>(res + (size_t)ppv[nt] * p_cout + co_);
+    }
   }
-  EPI_LOAD(0, 0);
   const bool want_stats = NT == 4 && kp.stats != nullptr;
   float* sp = want_stats ? kp.stats + ((size_t)((pn0 + wn * 64) >> 6) * p_cout) * 2 : nullptr;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const int slot = mt & 1;
     const int co = cm0 + wm * 16 * MT + mt * 16 + lq * 4;
-    bcur = kp.bias ? *reinterpret_cast<const float4*>(kp.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (mt + 1 < MT) { EPI_LOAD(slot ^ 1, mt + 1); }
+    const float4 bcur = bv[mt];
+    if (bnc) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        if (ppv[nt] >= 0) nv[nt] = *reinterpret_cast<const V4*>(bnc + (size_t)nsv[nt] * kp.ld_bias_nc + co);
+    }
     float ss4[4] = {0.f, 0.f, 0.f, 0.f}, sq4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -349,13 +366,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_ige
       v[2] = acc[mt][nt][2] + bcur.z; v[3] = acc[mt][nt][3] + bcur.w;
       if (bnc) {
         float f[4];
-        Vec4<T>::unpack(nv[slot][nt], f);
+        Vec4<T>::unpack(nv[nt], f);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += f[r];
       }
       if (res) {
         float f[4];
-        Vec4<T>::unpack(rv[slot][nt], f);
+        Vec4<T>::unpack(rv[mt][nt], f);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += f[r];
       }
@@ -385,7 +402,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_ige
       }
     }
   }
-#undef EPI_LOAD
 }
 
 // split-K second pass: fixed-order sum of the f32 slabs + the conv epilogue
