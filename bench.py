@@ -254,8 +254,16 @@ def main():
         hev.close()
         ach = fl / (ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[a.dtype]
+        traffic, tsrc = None, None
+        try:        # HBM bytes per launch of the dominant kernel from the committed PMC passes (cannot be collected in-process)
+            with open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic_pmc.json')) as f:
+                k = json.load(f)['kernels']['conv_igemm_kernel<bf16_t, 6, 4, 2, 2, 2>']
+            if a.dtype == 'bf16' and a.candidates == 64:
+                traffic, tsrc = round(k['hbm_bytes_per_launch']), 'profiles/r01_hbm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)'
+        except Exception:
+            pass
         roof = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                'traffic': None, 'kernel': 'conv_igemm_kernel', 'launches': len(rec),
+                'traffic': traffic, 'traffic_source': tsrc, 'kernel': 'conv_igemm_kernel', 'launches': len(rec),
                 'avg_launch_us': round(ms * 1e3 / len(rec), 2), 'avg_launch_gflop': round(fl / len(rec) / 1e9, 3),
                 'conv_ms_per_step': round(ms / min(2, a.steps), 2),
                 'whole_step_frac': round((value / world) * ADM_GFLOP_PER_EVAL * 1e9 / (peak * 1e12), 4)}
