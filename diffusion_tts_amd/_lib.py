@@ -54,6 +54,7 @@ SIGNATURES = {
     'dts_take_token': [_p, _i, _p, _i, _i, _i, _i, _p],
     'dts_softmax_gather': [_p, _p, _p, _i, _i, _p],
     'dts_candidate_noise': [_p, _p, _p, _p, _p, _i, _i, _i, _p],
+    'dts_cfg_combine': [_p, _p, _f, _p, _i, _i64, _p],
     'dts_ddim_candidates': [_p, _p, _p, _p, _p, _i, _f, _f, _f, _i, _i64, _p],
 }
 OTHER = {'dts_version': ([], _i), 'dts_last_error': ([], C.c_char_p), 'dts_gn_ws_floats': ([_i, _i], _i64)}

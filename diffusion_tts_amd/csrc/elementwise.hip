@@ -144,6 +144,22 @@ __global__ void quantize_kernel(const E* __restrict__ x, uint8_t* __restrict__ o
     out[i] = (uint8_t)v;                                   // truncation, as Tensor.to(torch.uint8)
   }
 }
+// SD backend: the image is f32 and the reference's affine map runs in f32 (pipeline_stable_diffusion.py:1116)
+__global__ void quantize_f32math_kernel(const float* __restrict__ x, uint8_t* __restrict__ out, long long count) {
+  GSL(i, count) {
+    float v = x[i] * 127.5f + 128.0f;
+    v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
+    out[i] = (uint8_t)v;
+  }
+}
+// classifier-free guidance: out = u + g*(c - u)   (pipeline_stable_diffusion.py:1072-1074)
+template <typename T>
+__global__ void cfg_combine_kernel(const T* __restrict__ u, const T* __restrict__ c, float g, T* __restrict__ out, long long count) {
+  GSL(i, count) {
+    const float uv = ld1<T>(u + i), cv = ld1<T>(c + i);
+    st1<T>(out + i, uv + g * (cv - uv));
+  }
+}
 // one block per image; u8/255 in f32, weighted channel sum in f32 (as the reference), spatial mean in f64
 __global__ __launch_bounds__(256) void brightness_kernel(const uint8_t* __restrict__ img, float* __restrict__ rewards, int hw) {
   __shared__ double red[4];
@@ -425,7 +441,9 @@ extern "C" int dts_heun_correct(const double* x_hat, const float* D2, const doub
 extern "C" int dts_quantize_u8(const void* x, int is_f32, uint8_t* out, int64_t count, dts_stream s) {
   DTS_CHECK_ARG(x && out && count > 0, "dts_quantize_u8: bad args");
   ST;
-  if (is_f32)
+  if (is_f32 == 2)
+    hipLaunchKernelGGL(quantize_f32math_kernel, dim3(grid1d(count)), dim3(256), 0, st, (const float*)x, out, (long long)count);
+  else if (is_f32)
     hipLaunchKernelGGL((quantize_kernel<float>), dim3(grid1d(count)), dim3(256), 0, st, (const float*)x, out, (long long)count);
   else
     hipLaunchKernelGGL((quantize_kernel<double>), dim3(grid1d(count)), dim3(256), 0, st, (const double*)x, out, (long long)count);
@@ -496,6 +514,17 @@ extern "C" int dts_candidate_noise(const double* pivot, const double* g, const i
   ST;
   hipLaunchKernelGGL(candidate_noise_kernel, dim3(nb), dim3(256), 0, st, pivot, g, mode, scale, cand, b, chw);
   DTS_CHECK_LAUNCH("dts_candidate_noise");
+  return DTS_OK;
+}
+
+extern "C" int dts_cfg_combine(const void* uncond, const void* cond, float guidance, void* out, int dtype, int64_t count, dts_stream s) {
+  DTS_CHECK_ARG(uncond && cond && out && count > 0, "dts_cfg_combine: bad args");
+  ST;
+  DTS_DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL((cfg_combine_kernel<T>), dim3(grid1d(count)), dim3(256), 0, st, (const T*)uncond, (const T*)cond, guidance, (T*)out,
+                       (long long)count);
+    DTS_CHECK_LAUNCH("dts_cfg_combine");
+  });
   return DTS_OK;
 }
 

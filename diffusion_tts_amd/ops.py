@@ -307,11 +307,21 @@ def heun_correct(x_hat, D2, d_cur, t_hat, t_next, x_next):
 
 
 # ---- scorer plumbing ----------------------------------------------------------------------------
-def quantize_u8(x):
+def quantize_u8(x, f32_math=False):
+    """(x*127.5+128).clip(0,255) truncated to uint8; f64 arithmetic (EDM loop) unless f32_math (SD loop, f32 input)."""
     if x.dtype not in (torch.float64, torch.float32):
         raise ValueError('quantize_u8: float64/float32 only')
+    if f32_math and x.dtype != torch.float32:
+        raise ValueError('f32_math needs a float32 input')
     out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
-    _call('dts_quantize_u8', _ptr(x), int(x.dtype == torch.float32), _ptr(out), x.numel())
+    _call('dts_quantize_u8', _ptr(x), 2 if f32_math else int(x.dtype == torch.float32), _ptr(out), x.numel())
+    return out
+
+
+def cfg_combine(uncond, cond, guidance):
+    out = torch.empty_like(uncond)
+    _call('dts_cfg_combine', _ptr(uncond, 'uncond'), _ptr(cond, 'cond', uncond.dtype), float(guidance), _ptr(out),
+          dt_code(uncond.dtype), uncond.numel())
     return out
 
 

@@ -32,8 +32,14 @@ class Scorer:
 
 
 def _as_u8_batch(images, device):
-    if isinstance(images, list):                      # list of PIL images (edm/scorers.py:31-34)
-        images = torch.stack([torch.from_numpy(np.array(im)).permute(2, 0, 1) for im in images])
+    if isinstance(images, list):                      # list of PIL images (edm/scorers.py:31-34) or of tensors (sd/scorers.py:31-51)
+        parts = []
+        for im in images:
+            if isinstance(im, torch.Tensor):
+                parts.append(im if im.dim() == 4 else im.unsqueeze(0))
+            else:
+                parts.append(torch.from_numpy(np.array(im)).permute(2, 0, 1).unsqueeze(0))
+        images = torch.cat([p.to(device) for p in parts], dim=0)
     if not isinstance(images, torch.Tensor):
         raise TypeError(f'unsupported image container {type(images)}')
     if images.dtype != torch.uint8:

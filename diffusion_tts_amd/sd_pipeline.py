@@ -1,0 +1,217 @@
+"""The SD backend's noise-trajectory-search loop (drop-in for the reference's modified
+`StableDiffusionPipeline.__call__`, sd/diffusers/.../pipeline_stable_diffusion.py:785-1485, from step 4 on) with
+candidate-BATCHED evaluation.
+
+BASELINE config 4 keeps the denoiser and the decoder as the stock diffusers modules ("diffusers U-Net path"): here
+`unet` and `vae` are opaque callables with the diffusers call surface
+    unet(sample, t, encoder_hidden_states=..., return_dict=False)[0]      vae.decode(z, return_dict=False)[0]
+What this build replaces is everything around them: the DDIM scheduler step fused over the N candidates that share one
+(x, eps) (`dts_ddim_candidates`, K13), classifier-free-guidance combine (`dts_cfg_combine`), quantisation (K10), and
+the loop structure -- the reference evaluates the N candidates of an iteration ONE AT A TIME (batch 2 through the
+U-Net, batch 1 through the VAE: pipeline...:1082-1129, 1383-1429); here all N go through the U-Net as one 2N-row call
+and through the VAE as one N-row call.  Values are unchanged: rows are independent.
+
+Host RNG: torch's CPU generator in the reference's call order (the pipeline's `--device cpu` run is the parity
+oracle), including the variance-noise draws `scheduler.step` makes and drops when called without `variance_noise`
+(scheduling_ddim.py:457-460).  Candidate construction (normalise + axpy, pipeline...:1371-1379) is a few KB of f32
+arithmetic on the host, bit-identical to the reference, then uploaded.
+
+Reference quirks kept: SD MCTS never scores or back-propagates (pipeline...:1201-1313), so every timestep takes the
+FIRST expanded child; its rollouts only consume RNG.  The draws are reproduced; the dead U-Net work is skipped unless
+`mcts_dead_compute=True`.
+"""
+import copy
+import types
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+class DDIMScheduler:
+    """Host mirror of the modified DDIMScheduler (scheduling_ddim.py): alpha table, `set_timesteps` ('leading' spacing),
+    `_get_variance`, and `step` routed to the fused HIP kernel.  Defaults = SD-1.5's scheduler_config.json."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, steps_offset=1, set_alpha_to_one=False):
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.num_train_timesteps, self.steps_offset = num_train_timesteps, steps_offset
+        self.num_inference_steps = None
+        self.init_noise_sigma = 1.0
+        self.order = 1
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        self.num_inference_steps = num_inference_steps
+        ratio = self.num_train_timesteps // num_inference_steps
+        ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64) + self.steps_offset
+        self.timesteps = torch.from_numpy(ts)
+        return self.timesteps
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def coefficients(self, timestep, eta=1.0):
+        """(alpha_t, alpha_prev, sigma_t) as f32 scalars (scheduling_ddim.py:403-405, 253-261, 431)."""
+        timestep = int(timestep)
+        prev = timestep - self.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[timestep]
+        a_p = self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod
+        var = ((1 - a_p) / (1 - a_t)) * (1 - a_t / a_p)
+        return float(a_t), float(a_p), float(eta * var ** 0.5)
+
+    def step(self, model_output, timestep, sample, eta=1.0, variance_noise=None, return_dict=False, generator=None):
+        """(prev_sample, pred_original_sample); variance_noise may hold N candidates ([N, *sample.shape]) -> N prev samples."""
+        a_t, a_p, sig = self.coefficients(timestep, eta)
+        if variance_noise is None and eta > 0:
+            variance_noise = torch.randn(model_output.shape, dtype=torch.float32).to(sample.device, sample.dtype)
+        z = variance_noise
+        if z is not None and z.dim() == sample.dim():
+            z = z.unsqueeze(0)
+        prev, x0 = ops.ddim_candidates(sample.contiguous(), model_output.contiguous(), None if z is None else z.contiguous(), a_t, a_p, sig)
+        if z is None or variance_noise.dim() == sample.dim():
+            prev = prev[0]
+        return prev, x0
+
+
+class SDSearchPipeline:
+    def __init__(self, unet, vae, scheduler: Optional[DDIMScheduler] = None, device='cuda', mcts_dead_compute=False):
+        self.unet, self.vae = unet, vae
+        self.scheduler = scheduler or DDIMScheduler()
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('SDSearchPipeline (HIP) needs a GPU device')
+        self.mcts_dead_compute = mcts_dead_compute
+        self.unet_rows = 0
+
+    # ------------------------------------------------------------------------------------------
+    def _eps(self, x, t, embeds_u, embeds_c, guidance):
+        """CFG noise prediction for a batch of latents: one 2n-row U-Net call (reference: n calls of 2 rows)."""
+        n = x.shape[0]
+        ehs = torch.cat([embeds_u.expand(n, -1, -1), embeds_c.expand(n, -1, -1)])
+        out = self.unet(torch.cat([x, x]), t, encoder_hidden_states=ehs, return_dict=False)[0].contiguous()
+        self.unet_rows += 2 * n
+        return ops.cfg_combine(out[:n].contiguous(), out[n:].contiguous(), guidance)
+
+    def _score(self, score_function, x0, prompt, scores):
+        """decode + quantise the batch once; the scorer keeps the reference's per-image calling convention."""
+        image = self.vae.decode(x0 / self.vae.config.scaling_factor, return_dict=False)[0].float().contiguous()
+        u8 = ops.quantize_u8(image, f32_math=True)
+        vals = []
+        for j in range(u8.shape[0]):
+            s = score_function(images=[u8[j:j + 1]], prompts=[prompt], timesteps=None)
+            vals.append(s.item() if torch.is_tensor(s) else float(s))
+        scores += vals
+        return vals
+
+    def _evaluate(self, noise_pred, t, x, cands_dev, eu, ec, g, eta, score_function, prompt, scores):
+        """candidates [N,1,C,H,W] -> (latents_cand [N,C,H,W], rewards): steps 1083-1114 of the reference for all N at once."""
+        a_t, a_p, sig = self.scheduler.coefficients(t, eta)
+        prev, _ = ops.ddim_candidates(x.contiguous(), noise_pred.contiguous(), cands_dev.contiguous(), a_t, a_p, sig, want_x0=False)
+        lat_c = prev.reshape(prev.shape[0], *x.shape[1:])
+        np2 = self._eps(lat_c, t, eu, ec, g)                                   # same t, not t-1 (:1090)
+        _, x0 = ops.ddim_candidates(lat_c.contiguous(), np2.contiguous(), None, a_t, a_p, sig)
+        return lat_c, self._score(score_function, x0, prompt, scores)
+
+    def _up(self, t, dtype):
+        return t.to(self.device, dtype).contiguous()
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, prompt=None, num_inference_steps=100, guidance_scale=7.5, eta=1.0, latents=None, prompt_embeds=None,
+                 negative_prompt_embeds=None, score_function: Optional[Callable] = None, method='eps_greedy', params=None,
+                 output_type='pt'):
+        if prompt_embeds is None or negative_prompt_embeds is None:
+            raise ValueError('pass prompt_embeds / negative_prompt_embeds (the text encoder is outside this path)')
+        sch, dev = self.scheduler, self.device
+        dtype = getattr(self.unet, 'dtype', torch.float32)
+        eu, ec = self._up(negative_prompt_embeds, dtype), self._up(prompt_embeds, dtype)
+        timesteps = sch.set_timesteps(num_inference_steps)
+        latents = self._up(latents * sch.init_noise_sigma, dtype)
+        shape = tuple(latents.shape)
+        scores, g = [], float(guidance_scale)
+        self.unet_rows = 0
+        randn = lambda: torch.randn(shape, dtype=torch.float32)               # randn_like(latents) on the reference's CPU run
+        max_score = None
+
+        if method == 'beam':
+            B, N = params['B'], params['N']
+            best = [copy.deepcopy(latents) for _ in range(B)]
+            for i, t in enumerate(timesteps):
+                scored, vals = [], []
+                for beam in best:
+                    noise_pred = self._eps(beam, t, eu, ec, g)
+                    cands = torch.stack([randn() for _ in range(N)])           # :1080
+                    for _ in range(N):
+                        randn()                                                # dropped variance noise of the second step (:1109)
+                    lat_c, v = self._evaluate(noise_pred, t, beam, self._up(cands, dtype), eu, ec, g, eta, score_function, prompt, scores)
+                    scored += [lat_c[j:j + 1] for j in range(N)]
+                    vals += v
+                order = sorted(range(len(vals)), key=lambda k: vals[k], reverse=True)      # stable: first wins ties (:1132)
+                best = [scored[k] for k in order[:B]]
+            max_score, latents = float('-inf'), best[0]
+            finals = self._score(score_function, torch.cat(best), prompt, scores)          # :1157-1170
+            for lat_c, v in zip(best, finals):
+                if v > max_score:
+                    max_score, latents = v, lat_c
+        elif method == 'mcts':
+            for i, t in enumerate(timesteps):
+                children = []
+                for _ in range(params['S']):
+                    node = latents
+                    if len(children) < params['N']:
+                        noise_pred = self._eps(node, t, eu, ec, g)
+                        child, _ = sch.step(noise_pred, t, node, eta, variance_noise=self._up(randn(), dtype))
+                        children.append(child)
+                        node = child
+                    tmp = node
+                    if self.mcts_dead_compute:
+                        self._eps(node, t, eu, ec, g)
+                    for j in range(i, len(timesteps)):                        # rollout: consumes RNG, result never used
+                        z = randn()
+                        if self.mcts_dead_compute:
+                            tmp, _ = sch.step(self._eps(tmp, timesteps[j], eu, ec, g), timesteps[j], tmp, eta, variance_noise=self._up(z, dtype))
+                if children:
+                    latents = children[0]
+        else:
+            for i, t in enumerate(timesteps):
+                noise_pred = self._eps(latents, t, eu, ec, g)
+                pivot = randn()                                                # :1366 (host copy; f32)
+                if method in ('eps_greedy', 'zero_order'):
+                    N = params['N']
+                    thr = params['eps'] if method == 'eps_greedy' else 0.0
+                    for _ in range(params['K']):
+                        cands = []
+                        for _ in range(N):
+                            r = torch.rand(1).item()
+                            if r < thr:
+                                cands.append(randn())
+                            else:
+                                u = randn()
+                                u = u / torch.norm(u)
+                                cands.append(pivot + u * torch.rand(1).item() * params['lambda'] *
+                                             np.sqrt(shape[-1] * shape[-2] * shape[-3]))
+                        for _ in range(N):
+                            randn()                                            # dropped variance noise (:1410)
+                        _, vals = self._evaluate(noise_pred, t, latents, self._up(torch.stack(cands), dtype), eu, ec, g, eta,
+                                                 score_function, prompt, scores)
+                        max_score = max(vals)
+                        pivot = cands[vals.index(max_score)]                   # first max (:1432-1433)
+                latents, _ = sch.step(noise_pred, t, latents, eta, variance_noise=self._up(pivot, dtype))
+        image = self.vae.decode(latents / self.vae.config.scaling_factor, return_dict=False)[0]
+        if max_score is None:
+            u8 = ops.quantize_u8(image.float().contiguous(), f32_math=True)
+            max_score = score_function(images=[u8], prompts=[prompt], timesteps=None)
+            scores.append(max_score.item() if torch.is_tensor(max_score) else float(max_score))
+        if output_type == 'latent':
+            images = latents
+        elif output_type == 'pt':
+            images = (image / 2 + 0.5).clamp(0, 1)
+        else:
+            import PIL.Image
+            arr = ((image / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).float().cpu().numpy() * 255).round().astype('uint8')
+            images = [PIL.Image.fromarray(a) for a in arr]
+        out = types.SimpleNamespace(images=images, nsfw_content_detected=None, latents=latents, scores=scores, unet_rows=self.unet_rows)
+        return out, max_score

@@ -131,7 +131,8 @@ int dts_heun_correct(const double* x_hat, const float* D2, const double* d_cur, 
                      double* x_next, int64_t count, dts_stream s);
 
 /* ---- K10/K11: scorer pre-processing and brightness reward (edm/main.py:126; scorers.py:38-52) ----- */
-/* u8 = trunc(clip(f64(x)*127.5+128, 0, 255)); x is f64 (is_f32=0) or f32; the arithmetic is f64 either way */
+/* u8 = trunc(clip(x*127.5+128, 0, 255)); x is f64 (is_f32=0) or f32 (1): arithmetic in f64 as the EDM loop's (.to(float64) first);
+ * is_f32=2: f32 input AND f32 arithmetic, as the SD loop's (pipeline_stable_diffusion.py:1116) */
 int dts_quantize_u8(const void* x, int is_f32, uint8_t* out, int64_t count, dts_stream s);
 /* rewards[n] = clamp(mean_hw(0.2126 R + 0.7152 G + 0.0722 B)/1, 0, 1) on u8/255 images NCHW [n][3][h][w] */
 int dts_brightness(const uint8_t* img, float* rewards, int n, int hw, dts_stream s);
@@ -157,6 +158,8 @@ int dts_candidate_noise(const double* pivot, const double* g, const int32_t* mod
 /* For i in [0,count): x0 = (x - sqrt(1-a_t) e)/sqrt(a_t); [e' = (x - sqrt(a_t) x0)/sqrt(1-a_t) == e];
  * prev[cand] = sqrt(a_prev) x0 + sqrt(1 - a_prev - sigma_t^2) e + sigma_t z[cand]; ncand candidates share
  * one (x, e).  f32 math on dtype storage (DTS_F16 as the reference; DTS_F32 for tests). */
+/* classifier-free guidance, out = uncond + guidance*(cond - uncond) (pipeline_stable_diffusion.py:1072-1074) */
+int dts_cfg_combine(const void* uncond, const void* cond, float guidance, void* out, int dtype, int64_t count, dts_stream s);
 int dts_ddim_candidates(const void* x, const void* e, const void* z, void* prev, void* x0_out, int dtype,
                         float alpha_t, float alpha_prev, float sigma_t, int ncand, int64_t count, dts_stream s);
 

@@ -35,8 +35,48 @@ def get_scorer(backend, scorer_name, device):
     if scorer_name == 'imagenet' and backend == 'edm':
         return S.ImageNetScorer(dtype=torch.float32, device=device)
     if scorer_name == 'clip' and backend == 'sd':
-        raise ValueError('the CLIP scorer needs the SD backend, which is not built yet (see below)')
+        raise ValueError('the CLIP scorer needs HF CLIP weights + tokenizer files, which are not available offline')
     raise ValueError(f"Unknown or invalid scorer '{scorer_name}' for backend '{backend}'")
+
+
+def main_sd(args):
+    """SD backend (reference main.py:111-147).  The search loop, the fused DDIM candidate step and candidate batching are
+    this build's (diffusion_tts_amd/sd_pipeline.py); the U-Net / VAE / text encoder are the stock diffusers / transformers
+    modules on PyTorch-ROCm, which must be importable and have SD-1.5 weights in the local HF cache (no network here)."""
+    try:
+        from diffusers import AutoencoderKL, UNet2DConditionModel          # noqa: F401
+        from transformers import CLIPTextModel, CLIPTokenizer              # noqa: F401
+    except Exception as e:      # pragma: no cover
+        raise RuntimeError('--backend sd needs `diffusers` (U-Net/VAE) and SD-1.5 weights in the local cache; neither is '
+                           'available in this image.  Drive diffusion_tts_amd.sd_pipeline.SDSearchPipeline(unet, vae) directly '
+                           '(tests/test_gpu_sd.py shows the call).') from e
+    from diffusion_tts_amd.sd_pipeline import SDSearchPipeline
+    model_id = 'runwayml/stable-diffusion-v1-5'
+    dev = torch.device(args.device)
+    unet = UNet2DConditionModel.from_pretrained(model_id, subfolder='unet', torch_dtype=torch.float16, local_files_only=True).to(dev)
+    vae = AutoencoderKL.from_pretrained(model_id, subfolder='vae', torch_dtype=torch.float16, local_files_only=True).to(dev)
+    tok = CLIPTokenizer.from_pretrained(model_id, subfolder='tokenizer', local_files_only=True)
+    te = CLIPTextModel.from_pretrained(model_id, subfolder='text_encoder', torch_dtype=torch.float16, local_files_only=True).to(dev)
+
+    def embed(text):
+        ids = tok(text, padding='max_length', max_length=tok.model_max_length, truncation=True, return_tensors='pt').input_ids.to(dev)
+        return te(ids)[0]
+    scorer = get_scorer('sd', args.scorer, dev)
+    pipe = SDSearchPipeline(unet, vae, device=dev)
+    params = {'N': args.N, 'lambda': args.lambda_, 'eps': args.eps, 'K': args.K, 'B': args.B, 'S': args.S}
+    best, best_score = None, float('-inf')
+    for _ in range(params['N'] if args.method == 'rejection' else 1):          # reference main.py:134
+        lat = torch.randn(1, unet.config.in_channels, unet.config.sample_size, unet.config.sample_size)
+        out, score = pipe(prompt=args.prompt, prompt_embeds=embed(args.prompt), negative_prompt_embeds=embed(''), latents=lat,
+                          num_inference_steps=50, score_function=scorer, method='naive' if args.method == 'rejection' else args.method,
+                          params=params, output_type='pil')
+        score = float(score.item() if torch.is_tensor(score) else score)
+        if score > best_score:
+            best, best_score = out, score
+    outname = args.output or f'sd_{args.method}_{args.scorer}.png'
+    best.images[0].save(outname)
+    print(f'\n[SD] Saved: {outname}\nBest score: {best_score}\n')
+    return best
 
 
 def main(argv=None):
@@ -66,9 +106,7 @@ def main(argv=None):
     if args.backend == 'edm' and args.scorer == 'clip':
         raise ValueError('clip scorer is only available for sd backend')
     if args.backend == 'sd':
-        raise NotImplementedError(
-            'SD backend: the search loop needs the (vendored, modified) diffusers U-Net/VAE, which is not installed here; '
-            'the fused DDIM candidate step it would call exists (dts_ddim_candidates); see DESIGN.md "out of scope".')
+        return main_sd(args)
     if not str(args.device).startswith('cuda'):
         raise RuntimeError(f"--device {args.device}: this build is the GPU path; the CPU path is the reference itself "
                            f"(its restatement lives in oracle/ as test infrastructure)")
