@@ -76,6 +76,7 @@ class _Loop:
         self.S_churn, self.S_min, self.S_max, self.S_noise = S_churn, S_min, S_max, S_noise
         self.scale_fn, self.shards = scale_fn, shards
         self.rewards, self.selected = [], []
+        self.reuse_winner = False
 
     def up(self, t, dtype=None):
         return t.to(self.dev, dtype).contiguous() if dtype is not None else t.to(self.dev).contiguous()
@@ -152,20 +153,35 @@ def _beam(L: _Loop, t_steps, x_next, labels, p, pre):
     raise RuntimeError('unreachable')
 
 
-def _eps_greedy(L: _Loop, t_steps, x_next, labels, p, pre):
-    """edm/main.py:714-860 (ZERO_ORDER and EPS_GREEDY share this branch in the reference)."""
-    lam = p.lambda_param * np.sqrt(3 * 64 * 64)            # scaled by 3*64*64 whatever the resolution (:716)
-    N, K, eps_p, B = p.N, p.K, p.eps, x_next.shape[0]
-    shape = tuple(x_next.shape)
-    lo, hi = L.shards.span(N)
-    nl = hi - lo
-    lab_l = None if labels is None else labels.repeat(nl, 1).contiguous()
-    pivot_h = pre['pivot'] if (pre is not None and 'pivot' in pre) else torch.randn(shape, dtype=torch.float64)   # :727
+class _Lookahead:
+    """Pulls items of a generator up to `depth` ahead of their use.  The search randomness never depends on search
+    results (only the pivot does), so the host can draw iteration k+1's numbers -- in the reference's order -- while the
+    GPU is still busy with iteration k."""
+
+    def __init__(self, gen, depth=2):
+        self.gen, self.depth, self.buf = gen, depth, []
+
+    def prefetch(self):
+        while len(self.buf) < self.depth:
+            try:
+                self.buf.append(next(self.gen))
+            except StopIteration:
+                break
+
+    def get(self):
+        if not self.buf:
+            self.prefetch()
+        return self.buf.pop(0)
+
+
+def _eps_greedy_draws(L, p, pre, shape, lam):
+    """The host-RNG stream of edm/main.py:724-797 in call order: per timestep one pivot, then per local-search
+    iteration the N coins / Gaussians / hash-derived scales."""
+    N, K, eps_p = p.N, p.K, p.eps
+    if not (pre is not None and 'pivot' in pre):
+        torch.randn(shape, dtype=torch.float64)                                       # :727, overwritten at :737
     for i in range(L.num_steps):
-        t_cur, t_next = t_steps[i], t_steps[i + 1]
-        x_cur = x_next
-        pivot_h = pre[f'pivot_{i}'] if (pre is not None and f'pivot_{i}' in pre) else torch.randn(shape, dtype=torch.float64)
-        pivot = L.up(pivot_h, torch.float64)
+        yield pre[f'pivot_{i}'] if (pre is not None and f'pivot_{i}' in pre) else torch.randn(shape, dtype=torch.float64)
         for k in range(K):
             g_h, mode, scale = [], [], []
             for n in range(N):
@@ -183,12 +199,30 @@ def _eps_greedy(L: _Loop, t_steps, x_next, labels, p, pre):
                     mode.append(0)
                     scale.append(0.0)
                 g_h.append(g)
-            mode_t = torch.tensor(mode, dtype=torch.int32)
-            scale_t = torch.tensor(scale, dtype=torch.float32)
+            yield g_h, torch.tensor(mode, dtype=torch.int32), torch.tensor(scale, dtype=torch.float32)
+
+
+def _eps_greedy(L: _Loop, t_steps, x_next, labels, p, pre):
+    """edm/main.py:714-860 (ZERO_ORDER and EPS_GREEDY share this branch in the reference)."""
+    lam = p.lambda_param * np.sqrt(3 * 64 * 64)            # scaled by 3*64*64 whatever the resolution (:716)
+    N, K, B = p.N, p.K, x_next.shape[0]
+    shape = tuple(x_next.shape)
+    lo, hi = L.shards.span(N)
+    nl = hi - lo
+    lab_l = None if labels is None else labels.repeat(nl, 1).contiguous()
+    draws = _Lookahead(_eps_greedy_draws(L, p, pre, shape, lam))
+    for i in range(L.num_steps):
+        t_cur, t_next = t_steps[i], t_steps[i + 1]
+        x_cur = x_next
+        pivot = L.up(draws.get(), torch.float64)
+        x_win = None
+        for k in range(K):
+            g_h, mode_t, scale_t = draws.get()
             g_l = L.up(torch.cat(g_h[lo:hi], dim=0))                                   # n-major rows (:800)
             cand = ops.candidate_noise(pivot, g_l, L.up(mode_t[lo:hi]), L.up(scale_t[lo:hi]))
-            _, x0 = L.step(x_cur, t_cur, t_next, i, cand, lab_l, nb=nl * B)
+            x_cand, x0 = L.step(x_cur, t_cur, t_next, i, cand, lab_l, nb=nl * B)
             loc = L.score(p.scorer, x0, lab_l).to(L.dev, torch.float32)
+            draws.prefetch()                                                           # host draws overlap the queued GPU work
             scores = L.shards.gather_rewards(loc, N, B).reshape(N, B).cpu()
             best = scores.argmax(dim=0)                                                # first max (:842)
             L.rewards.append(scores)
@@ -202,7 +236,18 @@ def _eps_greedy(L: _Loop, t_steps, x_next, labels, p, pre):
                 rows = [ops.candidate_noise(pivot[b:b + 1].contiguous(), L.up(g_w[b:b + 1]), L.up(mode_t[j:j + 1]),
                                             L.up(scale_t[j:j + 1])) for b, j in enumerate(bl)]
                 pivot = torch.cat(rows, dim=0)
-        x_next, _ = L.step(x_cur, t_cur, t_next, i, pivot, labels)                     # :860
+            if L.reuse_winner and k == K - 1:
+                # the step the reference recomputes at :860 for the final pivot IS the winner's row of this iteration
+                rows = []
+                for b, j in enumerate(bl):
+                    own = lo <= j < hi
+                    r = x_cand[(j - lo) * B + b].clone() if own else torch.empty(shape[1:], dtype=torch.float64, device=L.dev)
+                    rows.append(L.shards.broadcast_from_owner(r, j, N))
+                x_win = torch.stack(rows)
+        if x_win is not None:
+            x_next = x_win
+        else:
+            x_next, _ = L.step(x_cur, t_cur, t_next, i, pivot, labels)                 # :860
     return x_next
 
 
@@ -318,9 +363,10 @@ def generate_image_grid(
     sampling_params: Optional[Dict[str, Any]] = None,
     precomputed_noise: Optional[Dict[Any, torch.Tensor]] = None,
     *, scale_fn: Callable[[int, int, int], float] = builtin_scale, compute_dtype=torch.bfloat16, verbose=True,
+    reuse_winner: Optional[bool] = None,
 ):
     """Same positional/keyword surface as edm/main.py:47-55.  Keyword-only extras: `scale_fn` (the hash-derived step
-    table, edm/main.py:776), `compute_dtype` (float32 = parity mode), `verbose`.  Writes the PNG grid like the
+    table, edm/main.py:776), `compute_dtype` (float32 = parity mode), `verbose`, `reuse_winner` (see below).  Writes the PNG grid like the
     reference when `dest_path` is not None and additionally returns a dict with the final state and the search trace."""
     device = torch.device(device)
     if device.type != 'cuda':
@@ -335,6 +381,9 @@ def generate_image_grid(
     t_steps = (sigma_max ** (1 / rho) + step_indices / (num_steps - 1) * (sigma_min ** (1 / rho) - sigma_max ** (1 / rho))) ** rho
     t_steps = torch.cat([net.round_sigma(t_steps), torch.zeros_like(t_steps[:1])])
     L = _Loop(net, device, num_steps, S_churn, S_min, S_max, S_noise, scale_fn, shards)
+    # eps-greedy: the reference re-runs step() at batch 1 for the final pivot of each timestep (edm/main.py:860) although
+    # that row was just computed in the last candidate batch.  Throughput modes reuse it; parity mode recomputes.
+    L.reuse_winner = (compute_dtype != torch.float32) if reuse_winner is None else bool(reuse_winner)
     x0 = (latents.to(torch.float64).cpu() * t_steps[0]).to(device).contiguous()       # edm/main.py:99
     labels = None if class_labels is None else class_labels.to(device, torch.float32).contiguous()
     evals0 = getattr(net, 'evals', 0)

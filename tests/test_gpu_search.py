@@ -84,7 +84,7 @@ def test_brightness_and_compressibility_scorers(pkg, golden):
     assert np.array_equal(j.numpy(), golden['score_jpeg'])
 
 
-def run_case(pkg, golden, manifest, case, dtype):
+def run_case(pkg, golden, manifest, case, dtype, **extra):
     meta = manifest['cases'][case]
     net = hip_net(pkg, manifest, meta['net'], dtype)
     S = pkg['scorers']
@@ -101,7 +101,7 @@ def run_case(pkg, golden, manifest, case, dtype):
                                  num_steps=meta['num_steps'], S_churn=40, S_min=0.05, S_max=50, S_noise=1.003,
                                  sampling_method=getattr(sm.SamplingMethod, meta['method']),
                                  sampling_params=dict(scorer=scorer, **meta['params']),
-                                 scale_fn=seed0_scale, compute_dtype=dtype, verbose=False)
+                                 scale_fn=seed0_scale, compute_dtype=dtype, verbose=False, **extra)
     return meta, res
 
 
@@ -155,6 +155,16 @@ def test_search_throughput_modes_stay_close(pkg, golden, manifest, dtype):
     agree = np.mean([np.array_equal(sel.numpy(), golden[f'epsgreedy_adm_bright_score{j}'].reshape(4, 2).argmax(axis=0))
                      for j, sel in enumerate(res['selected'])])
     assert agree >= 0.5, agree
+
+
+def test_reusing_the_winners_row_changes_nothing(pkg, golden, manifest):
+    """throughput modes skip the batch-1 recomputation of the final pivot's step (edm/main.py:860) and take the winner's
+    row of the last candidate batch: same selections, same image, 35*... fewer denoiser rows."""
+    meta, a = run_case(pkg, golden, manifest, 'epsgreedy_adm_bright', torch.float32, reuse_winner=False)
+    _, b = run_case(pkg, golden, manifest, 'epsgreedy_adm_bright', torch.float32, reuse_winner=True)
+    assert all(torch.equal(x, y) for x, y in zip(a['selected'], b['selected']))
+    assert (a['x'] - b['x']).abs().max().item() < 1e-5
+    assert b['net_rows'] < a['net_rows'] == meta['net_rows']
 
 
 def test_beam_raises_like_the_reference(pkg, golden, manifest):
