@@ -25,6 +25,8 @@
 namespace {
 
 thread_local bool g_stats_written = false;
+int g_persist = 0;             // DTS_CONV_PERSIST=1 enables the persistent (cross-tile prefetch) variant: measured no faster
+                               // than letting the hardware interleave two resident blocks per CU (profiles/r01_conv_variants.txt)
 
 struct ConvP {
   const char* x1; const char* x2;
@@ -138,11 +140,120 @@ __device__ __forceinline__ void glds16(const char* g, uint32_t lds_off) {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
+// ---- epilogue of one (cout tile, pixel tile[, K split]): lane holds couts co..co+3 of pixel pp for each (mt, nt)
+template <typename T, int MT, int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT][NT], int cm0, int pn0, int split, int wm, int wn,
+                                              int lrow, int lq) {
+  const int p_P = kp.P, p_cout = kp.cout, p_hout = kp.hout, p_wout = kp.wout;
+  // ---- epilogue: lane holds couts co..co+3 of pixel pp for each (mt, nt): one 4-element vector load/store
+  if (kp.splits > 1) {
+    float* part = kp.partial + (size_t)split * p_P * p_cout;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int pp = pn0 + wn * 16 * NT + nt * 16 + lrow;
+      if (pp >= p_P) continue;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int co = cm0 + wm * 16 * MT + mt * 16 + lq * 4;
+        *reinterpret_cast<float4*>(part + (size_t)pp * p_cout + co) =
+            make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+      }
+    }
+    return;
+  }
+  // Epilogue, one 16-cout slice (mt) at a time; interleaved load->store pairs would serialise a memory round trip per
+  // (mt, nt) because the compiler must assume `out` aliases the inputs, so the reads are hoisted by hand.
+  const T* __restrict__ res = reinterpret_cast<const T*>(kp.residual);
+  const T* __restrict__ bnc = reinterpret_cast<const T*>(kp.bias_nc);
+  T* __restrict__ out = reinterpret_cast<T*>(kp.out);
+  const int hw = p_hout * p_wout;
+  using V4 = typename Vec4<T>::type;
+  int ppv[NT], nsv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int pp = pn0 + wn * 16 * NT + nt * 16 + lrow;
+    ppv[nt] = pp < p_P ? pp : -1;
+    nsv[nt] = pp < p_P ? pp / hw : 0;
+  }
+  // residual vectors: all MT*NT reads in flight before the first store (a memory round trip per slice otherwise);
+  // the rarer per-sample bias (SongUNet's conv0) is fetched per slice to keep the register budget under 256.
+  V4 rv[MT][NT], nv[NT];
+  float4 bv[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+    bv[mt] = kp.bias ? *reinterpret_cast<const float4*>(kp.bias + cm0 + wm * 16 * MT + mt * 16 + lq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  if (res) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int co_ = cm0 + wm * 16 * MT + mt * 16 + lq * 4;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        if (ppv[nt] >= 0) rv[mt][nt] = *reinterpret_cast<const V4*>(res + (size_t)ppv[nt] * p_cout + co_);
+    }
+  }
+  const bool want_stats = NT == 4 && kp.stats != nullptr;
+  float* sp = want_stats ? kp.stats + ((size_t)((pn0 + wn * 64) >> 6) * p_cout) * 2 : nullptr;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int co = cm0 + wm * 16 * MT + mt * 16 + lq * 4;
+    const float4 bcur = bv[mt];
+    if (bnc) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        if (ppv[nt] >= 0) nv[nt] = *reinterpret_cast<const V4*>(bnc + (size_t)nsv[nt] * kp.ld_bias_nc + co);
+    }
+    float ss4[4] = {0.f, 0.f, 0.f, 0.f}, sq4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (ppv[nt] < 0) continue;
+      float v[4];
+      v[0] = acc[mt][nt][0] + bcur.x; v[1] = acc[mt][nt][1] + bcur.y;
+      v[2] = acc[mt][nt][2] + bcur.z; v[3] = acc[mt][nt][3] + bcur.w;
+      if (bnc) {
+        float f[4];
+        Vec4<T>::unpack(nv[nt], f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += f[r];
+      }
+      if (res) {
+        float f[4];
+        Vec4<T>::unpack(rv[mt][nt], f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += f[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= kp.out_scale;
+      const V4 pk = Vec4<T>::pack(v);
+      *reinterpret_cast<V4*>(out + (size_t)ppv[nt] * p_cout + co) = pk;
+      if (want_stats) {                                // moments of the values as stored (rounded to T)
+        float f[4];
+        Vec4<T>::unpack(pk, f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ss4[r] += f[r]; sq4[r] += f[r] * f[r]; }
+      }
+    }
+    if (want_stats) {
+      // Fused GroupNorm statistics (input moments of the next networks.py:104-106 norm): this wave covers one 64-pixel
+      // strip; fixed-order reduction over the 16 pixel lanes, (sum, sumsq) per (strip, cout).  No atomics.
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { ss4[r] += __shfl_xor(ss4[r], o, 64); sq4[r] += __shfl_xor(sq4[r], o, 64); }
+      }
+      if (lrow == 0 && pn0 + wn * 64 < p_P) {
+        float4* d = reinterpret_cast<float4*>(sp + (size_t)co * 2);
+        d[0] = make_float4(ss4[0], sq4[0], ss4[1], sq4[1]);
+        d[1] = make_float4(ss4[2], sq4[2], ss4[3], sq4[3]);
+      }
+    }
+  }
+}
+
 template <typename T, int MT, int NT, int WM, int WN, int STAGES>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_igemm_kernel(const ConvP kp) {
   const char* const p_x1 = kp.x1; const char* const p_x2 = kp.x2; const char* const p_w = kp.w;
   const int p_c1 = kp.c1, p_c2 = kp.c2, p_cin = kp.cin, p_hin = kp.hin, p_win = kp.win, p_hout = kp.hout, p_wout = kp.wout;
-  const int p_taps = kp.taps, p_up = kp.up, p_P = kp.P, p_cout = kp.cout, p_n_ct = kp.n_ct, p_n_pt = kp.n_pt;
+  const int p_taps = kp.taps, p_up = kp.up, p_P = kp.P, p_n_ct = kp.n_ct, p_n_pt = kp.n_pt;
   constexpr int NW = WM * WN;              // waves per block (4: two blocks per CU; 8: one block per CU, 3-stage ring)
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per block");
   static_assert(STAGES == 2 || STAGES == 3, "2- or 3-stage LDS ring");
@@ -300,108 +411,141 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_ige
     buf = buf + 1 == STAGES ? 0 : buf + 1;
   }
 
-  // ---- epilogue: lane holds couts co..co+3 of pixel pp for each (mt, nt): one 4-element vector load/store
-  if (kp.splits > 1) {
-    float* part = kp.partial + (size_t)blockIdx.y * p_P * p_cout;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int pp = pn0 + wn * 16 * NT + nt * 16 + lrow;
-      if (pp >= p_P) continue;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int co = cm0 + wm * 16 * MT + mt * 16 + lq * 4;
-        *reinterpret_cast<float4*>(part + (size_t)pp * p_cout + co) =
-            make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
-      }
-    }
-    return;
+  conv_epilogue<T, MT, NT>(kp, acc, cm0, pn0, (int)blockIdx.y, wm, wn, lrow, lq);
+}
+
+// ---- persistent variant: each block walks work items (pixel tile x cout tile x K split) v = blockIdx.x, +gridDim.x, ...
+// and keeps ONE continuous double-buffered tile stream across them: during the last K step of an item the first tile of
+// the next item is already issued, so its load latency and the item's epilogue (global reads/stores only) overlap.
+// Layers with few K steps (1x1 convs: 6-12; the 64x64 level: 27) otherwise spend a quarter to a half of each block's
+// life in an exposed prologue load and an epilogue with an idle MFMA pipe.
+template <typename T, int MT, int NT, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_persist_kernel(const ConvP kp) {
+  const char* const p_x1 = kp.x1; const char* const p_x2 = kp.x2; const char* const p_w = kp.w;
+  const int p_c1 = kp.c1, p_c2 = kp.c2, p_cin = kp.cin, p_hin = kp.hin, p_win = kp.win, p_hout = kp.hout, p_wout = kp.wout;
+  const int p_taps = kp.taps, p_up = kp.up, p_P = kp.P, p_n_ct = kp.n_ct, p_n_pt = kp.n_pt;
+  static_assert(WM * WN == 4, "4 waves per block");
+  constexpr int SLAB = 32;
+  constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
+  constexpr int EPV = ET<T>::EPV, BKE = 8 * EPV, ES = 16 / EPV;
+  constexpr int RA = BM / SLAB, RB = BN / SLAB;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int nblk = p_n_ct * p_n_pt;
+  const int total = nblk * kp.splits;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid % WM, wn = wid / WM;
+  const int chunk = tid & 7, r0 = tid >> 3;
+  const int lrow = lane & 15, lq = lane >> 4;
+  const int K = p_taps * p_cin;
+  const int steps_per_tap = p_cin / BKE;
+  const int nk_all = p_taps * steps_per_tap;
+  const int schunk = (chunk ^ (r0 & 7)) * 16;
+  const char* zsrc = reinterpret_cast<const char*>(g_zero16);
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const uint32_t wave_rows = __builtin_amdgcn_readfirstlane(lds_base + (tid >> 6) * 8 * 128);
+
+  // issue-side state (runs one tile ahead of the compute side, possibly already in the next work item)
+  int pix_n[RB], pix_hw[RB], src_pix[RB];
+  const char* wsrc;
+  int tap, ci0, ks_i;                   // K position of the tile being issued
+  int i_cm0, i_pn0, i_split, i_ks_begin, i_ks_end;
+
+#define P_SETUP_ITEM(v_)                                                                                      \
+  {                                                                                                           \
+    const int sp_ = (v_) / nblk;                                                                              \
+    int t_ = (v_) - sp_ * nblk;                                                                               \
+    {                                                                                                         \
+      const int q = nblk >> 3, r = nblk & 7, xcd = t_ & 7, j = t_ >> 3;                                       \
+      t_ = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;                                       \
+    }                                                                                                         \
+    const int ct_ = t_ % p_n_ct, pt_ = t_ / p_n_ct;                                                           \
+    i_cm0 = ct_ * BM; i_pn0 = pt_ * BN; i_split = sp_;                                                        \
+    i_ks_begin = sp_ * kp.ks_per_split;                                                                       \
+    i_ks_end = min(nk_all, i_ks_begin + kp.ks_per_split);                                                     \
+    _Pragma("unroll") for (int j = 0; j < RB; ++j) {                                                          \
+      const int pp = i_pn0 + r0 + SLAB * j;                                                                   \
+      if (pp < p_P) {                                                                                         \
+        const int hw = p_hout * p_wout;                                                                       \
+        const int n = pp / hw, rem = pp - n * hw;                                                             \
+        const int ho = rem / p_wout, wo = rem - ho * p_wout;                                                  \
+        pix_n[j] = n * p_hin * p_win;                                                                         \
+        pix_hw[j] = (ho << 16) | wo;                                                                          \
+      } else {                                                                                                \
+        pix_n[j] = -1;                                                                                        \
+        pix_hw[j] = 0;                                                                                        \
+      }                                                                                                       \
+    }                                                                                                         \
+    wsrc = p_w + ((size_t)(i_cm0 + r0) * K) * ES + schunk;                                                    \
+    ks_i = i_ks_begin;                                                                                        \
+    tap = ks_i / steps_per_tap;                                                                               \
+    ci0 = (ks_i - tap * steps_per_tap) * BKE;                                                                 \
+    SET_TAP(tap);                                                                                             \
   }
-  // Epilogue, one 16-cout slice (mt) at a time; interleaved load->store pairs would serialise a memory round trip per
-  // (mt, nt) because the compiler must assume `out` aliases the inputs, so the reads are hoisted by hand.
-  const T* __restrict__ res = reinterpret_cast<const T*>(kp.residual);
-  const T* __restrict__ bnc = reinterpret_cast<const T*>(kp.bias_nc);
-  T* __restrict__ out = reinterpret_cast<T*>(kp.out);
-  const int hw = p_hout * p_wout;
-  using V4 = typename Vec4<T>::type;
-  int ppv[NT], nsv[NT];
+
+  int v = blockIdx.x;
+  if (v >= total) return;
+  P_SETUP_ITEM(v);
+  ISSUE_TILE(0, ks_i, ci0);
+  int buf = 0;
+  f32x4_t acc[MT][NT];
+  while (true) {
+    // compute-side description of item v (the issue side still points at it: nothing beyond its first tile is issued)
+    const int c_cm0 = i_cm0, c_pn0 = i_pn0, c_split = i_split, nsteps = i_ks_end - i_ks_begin;
+    const int vnext = v + gridDim.x;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int pp = pn0 + wn * 16 * NT + nt * 16 + lrow;
-    ppv[nt] = pp < p_P ? pp : -1;
-    nsv[nt] = pp < p_P ? pp / hw : 0;
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int s_ = 0; s_ < nsteps; ++s_) {
+      const char* sa = smem + buf * STAGE_BYTES + (wm * 16 * MT) * 128;
+      const char* sb = smem + buf * STAGE_BYTES + A_BYTES + (wn * 16 * NT) * 128;
+      uint4 fa[MT], fb[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq));
+#pragma unroll
+      for (int i = 0; i < NT; ++i) fb[i] = *reinterpret_cast<const uint4*>(sb + swz(i * 16 + lrow, lq));
+      // next tile of the stream into the other buffer (last read one step ago; every wave has passed that barrier)
+      if (s_ + 1 < nsteps) {
+        ++ks_i;
+        ADVANCE_K();
+        ISSUE_TILE(buf ^ 1, ks_i, ci0);
+      } else if (vnext < total) {
+        P_SETUP_ITEM(vnext);
+        ISSUE_TILE(buf ^ 1, ks_i, ci0);
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
+      __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq + 4));
+#pragma unroll
+      for (int i = 0; i < NT; ++i) fb[i] = *reinterpret_cast<const uint4*>(sb + swz(i * 16 + lrow, lq + 4));
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
+      __builtin_amdgcn_s_setprio(0);
+      if (s_ + 1 < nsteps) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the next item's first tile stays in flight over the epilogue
+      }
+      buf ^= 1;
+    }
+    conv_epilogue<T, MT, NT>(kp, acc, c_cm0, c_pn0, c_split, wm, wn, lrow, lq);
+    if (vnext >= total) break;
+    v = vnext;
   }
-  // residual vectors: all MT*NT reads in flight before the first store (a memory round trip per slice otherwise);
-  // the rarer per-sample bias (SongUNet's conv0) is fetched per slice to keep the register budget under 256.
-  V4 rv[MT][NT], nv[NT];
-  float4 bv[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-    bv[mt] = kp.bias ? *reinterpret_cast<const float4*>(kp.bias + cm0 + wm * 16 * MT + mt * 16 + lq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-  if (res) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int co_ = cm0 + wm * 16 * MT + mt * 16 + lq * 4;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        if (ppv[nt] >= 0) rv[mt][nt] = *reinterpret_cast<const V4*>(res + (size_t)ppv[nt] * p_cout + co_);
-    }
-  }
-  const bool want_stats = NT == 4 && kp.stats != nullptr;
-  float* sp = want_stats ? kp.stats + ((size_t)((pn0 + wn * 64) >> 6) * p_cout) * 2 : nullptr;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int co = cm0 + wm * 16 * MT + mt * 16 + lq * 4;
-    const float4 bcur = bv[mt];
-    if (bnc) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        if (ppv[nt] >= 0) nv[nt] = *reinterpret_cast<const V4*>(bnc + (size_t)nsv[nt] * kp.ld_bias_nc + co);
-    }
-    float ss4[4] = {0.f, 0.f, 0.f, 0.f}, sq4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      if (ppv[nt] < 0) continue;
-      float v[4];
-      v[0] = acc[mt][nt][0] + bcur.x; v[1] = acc[mt][nt][1] + bcur.y;
-      v[2] = acc[mt][nt][2] + bcur.z; v[3] = acc[mt][nt][3] + bcur.w;
-      if (bnc) {
-        float f[4];
-        Vec4<T>::unpack(nv[nt], f);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += f[r];
-      }
-      if (res) {
-        float f[4];
-        Vec4<T>::unpack(rv[mt][nt], f);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += f[r];
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] *= kp.out_scale;
-      const V4 pk = Vec4<T>::pack(v);
-      *reinterpret_cast<V4*>(out + (size_t)ppv[nt] * p_cout + co) = pk;
-      if (want_stats) {                                // moments of the values as stored (rounded to T)
-        float f[4];
-        Vec4<T>::unpack(pk, f);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { ss4[r] += f[r]; sq4[r] += f[r] * f[r]; }
-      }
-    }
-    if (want_stats) {
-      // Fused GroupNorm statistics (input moments of the next networks.py:104-106 norm): this wave covers one 64-pixel
-      // strip; fixed-order reduction over the 16 pixel lanes, (sum, sumsq) per (strip, cout).  No atomics.
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { ss4[r] += __shfl_xor(ss4[r], o, 64); sq4[r] += __shfl_xor(sq4[r], o, 64); }
-      }
-      if (lrow == 0 && pn0 + wn * 64 < p_P) {
-        float4* d = reinterpret_cast<float4*>(sp + (size_t)co * 2);
-        d[0] = make_float4(ss4[0], sq4[0], ss4[1], sq4[1]);
-        d[1] = make_float4(ss4[2], sq4[2], ss4[3], sq4[3]);
-      }
-    }
-  }
+#undef P_SETUP_ITEM
 }
 
 // split-K second pass: fixed-order sum of the f32 slabs + the conv epilogue
@@ -471,7 +615,19 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<T, MT, NT, WM, WN, STAGES>), dim3(nblk, splits), dim3(64 * NW), lds, st, q);
+  if (NW == 4 && STAGES == 2 && g_persist && nblk * splits > slots) {
+    if constexpr (NW == 4 && STAGES == 2) {
+      static bool attr2_done = false;
+      if (!attr2_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_persist_kernel<T, MT, NT, WM, WN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr2_done = true;
+      }
+      hipLaunchKernelGGL((conv_igemm_persist_kernel<T, MT, NT, WM, WN>), dim3(slots), dim3(256), lds, st, q);
+    }
+  } else {
+    hipLaunchKernelGGL((conv_igemm_kernel<T, MT, NT, WM, WN, STAGES>), dim3(nblk, splits), dim3(64 * NW), lds, st, q);
+  }
   DTS_CHECK_LAUNCH("dts_conv2d");
   if (splits > 1) {
     long long g = ((long long)p.P * (p.cout / 4) + 255) / 256;
@@ -492,6 +648,8 @@ int conv_dispatch(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes)
     g_tile_override = e ? atoi(e) : 0;
     const char* f = getenv("DTS_CONV_IMPL");
     g_impl_override = f ? atoi(f) : 0;
+    const char* pz = getenv("DTS_CONV_PERSIST");
+    if (pz) g_persist = atoi(pz);
   }
   int tile = (p.cout % 192 == 0) ? 192 : (p.cout % 128 == 0 ? 128 : 64);    // measured: tools/conv_bench.py
   if (g_tile_override > 0 && p.cout % g_tile_override == 0) tile = g_tile_override;

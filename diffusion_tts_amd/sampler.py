@@ -266,6 +266,7 @@ def _mcts(L: _Loop, t_steps, x_next, labels, p, pre):
     b, S, B, ns = p.N, p.S, x_next.shape[0], L.num_steps
     shape1 = tuple(x_next.shape[1:])
     results = []
+    L.shards.sync_numpy_rng()                         # replicas must draw the same rollout children (edm/main.py:593)
     mbs = min(2, B)
     for mb0 in range(0, B, mbs):
         xb = x_next[mb0:mb0 + mbs]
@@ -318,18 +319,26 @@ def _mcts(L: _Loop, t_steps, x_next, labels, p, pre):
                         path.append(node)
                     paths.append(path)
                     starts.append((node.x, it, s))
-                # batched ragged rollouts
-                cur = [x1.clone() for x1, _, _ in starts]
-                for j in range(min(it for _, it, _ in starts), ns):
-                    act = [q for q, (_, it, _) in enumerate(starts) if it <= j]
-                    xa = torch.cat([cur[q] for q in act], dim=0)
-                    la = None if lb is None else torch.cat([lb[starts[q][2]:starts[q][2] + 1] for q in act], dim=0).contiguous()
-                    xo, _ = L.step(xa, t_steps[j], t_steps[j + 1], j, torch.zeros_like(xa), la)
-                    for r_, q in enumerate(act):
-                        cur[q] = xo[r_:r_ + 1]
-                den = torch.cat(cur, dim=0)
-                sl = None if lb is None else torch.cat([lb[s:s + 1] for _, _, s in starts], dim=0).contiguous()
-                rew = L.score(p.scorer, den, sl).cpu()
+                # batched ragged rollouts; sharded: rank r advances the simulations [lo, hi) of this group and the
+                # group's rewards are all-gathered (the tree itself is replicated: SURVEY.md section 8e)
+                nsim = len(starts)
+                slo, shi = L.shards.span(nsim)
+                mine = list(range(slo, shi))
+                cur = {q: starts[q][0].clone() for q in mine}
+                if mine:
+                    for j in range(min(starts[q][1] for q in mine), ns):
+                        act = [q for q in mine if starts[q][1] <= j]
+                        xa = torch.cat([cur[q] for q in act], dim=0)
+                        la = None if lb is None else torch.cat([lb[starts[q][2]:starts[q][2] + 1] for q in act], dim=0).contiguous()
+                        xo, _ = L.step(xa, t_steps[j], t_steps[j + 1], j, torch.zeros_like(xa), la)
+                        for r_, q in enumerate(act):
+                            cur[q] = xo[r_:r_ + 1]
+                    den = torch.cat([cur[q] for q in mine], dim=0)
+                    sl = None if lb is None else torch.cat([lb[starts[q][2]:starts[q][2] + 1] for q in mine], dim=0).contiguous()
+                    loc = L.score(p.scorer, den, sl).to(L.dev, torch.float32)
+                else:
+                    loc = torch.empty(0, dtype=torch.float32, device=L.dev)
+                rew = L.shards.gather_rewards(loc, nsim, 1).cpu()
                 L.rewards.append(rew)
                 for path, r in zip(paths, rew):
                     for nd in path:

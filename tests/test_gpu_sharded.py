@@ -1,0 +1,85 @@
+"""GPU, 2 ranks (sharing the one GPU of the test box; gloo rendezvous on 127.0.0.1): the candidate-sharded search loop
+gives the same rewards, the same selected candidates and the same final image as the single-process loop, for
+rejection, eps-greedy and MCTS, with exactly one reward collective per search iteration."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+from helpers import tiny_edm                    # noqa: E402
+from diffusion_tts_amd.hashing import seed0_scale   # noqa: E402
+
+CASES = [('REJECTION_SAMPLING', dict(N=5), 2), ('EPS_GREEDY', dict(N=5, K=2, lambda_param=0.15, eps=0.4), 1),
+         ('EPS_GREEDY', dict(N=4, K=2, lambda_param=0.15, eps=0.4), 2), ('MCTS', dict(N=2, S=5), 1)]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _run(manifest, golden_path, use_dist):
+    import torch.distributed as dist
+    from diffusion_tts_amd.networks import EDMPrecond
+    from diffusion_tts_amd.sampler import SamplingMethod, generate_image_grid
+    from diffusion_tts_amd.scorers import BrightnessScorer
+    g = np.load(golden_path)
+    cfg, sd = tiny_edm(manifest, 'adm_tiny')
+    net = EDMPrecond(cfg, sd, device='cuda', dtype=torch.float32)
+    out = []
+    for method, params, b in CASES:
+        lat, lab = torch.from_numpy(g[f'search_latents{b}']), torch.from_numpy(g[f'search_lab{b}'])
+        np.random.seed(0 if (not use_dist or dist.get_rank() == 0) else 12345)     # ranks start with DIFFERENT numpy states
+        res = generate_image_grid(net, None, lat, lab, seed=3, gridw=b, gridh=1, device=torch.device('cuda'), num_steps=4,
+                                  S_churn=40, S_min=0.05, S_max=50, S_noise=1.003, sampling_method=getattr(SamplingMethod, method),
+                                  sampling_params=dict(scorer=BrightnessScorer(), **params), scale_fn=seed0_scale,
+                                  compute_dtype=torch.float32, verbose=False)
+        out.append(dict(x=res['x'].cpu().numpy(), rewards=[r.float().reshape(-1).numpy().copy() for r in res['rewards']],
+                        selected=[s.numpy().copy() for s in res['selected']], collectives=res['collectives'], rows=res['net_rows']))   # numpy: plain pickling through the mp queue
+    return out
+
+
+def _worker(rank, world, port, manifest, golden_path, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        q.put((rank, _run(manifest, golden_path, True)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_search_equals_single_process(manifest):
+    from conftest import ROOT
+    gp = os.path.join(ROOT, 'tests', 'golden', 'edm_golden.npz')
+    single = _run(manifest, gp, False)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, manifest, gp, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for ci, (method, params, b) in enumerate(CASES):
+        ref = single[ci]
+        for r in (0, 1):
+            me = got[r][ci]
+            assert len(me['rewards']) == len(ref['rewards'])
+            for a, c in zip(me['rewards'], ref['rewards']):
+                assert np.allclose(a, c, atol=2e-6), (method, r)
+            assert all(np.array_equal(a, c) for a, c in zip(me['selected'], ref['selected'])), (method, r)
+            assert np.abs(me['x'] - ref['x']).max() < 1e-5, (method, r)
+            assert me['rows'] < ref['rows'] or method == 'MCTS'          # each rank pushes fewer rows through the denoiser
+        if method == 'EPS_GREEDY':
+            assert got[0][ci]['collectives'] == 4 * params['K']          # ONE reward all-gather per search iteration
+        if method == 'REJECTION_SAMPLING':
+            assert got[0][ci]['collectives'] == 1 + b                    # rewards once + the winner's image per sample
