@@ -131,13 +131,20 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    ndev = max(1, torch.cuda.device_count())
+    dev = torch.device('cuda', (local % ndev) if world > 1 else 0)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        torch.cuda.set_device(dev)
+        # RCCL over xGMI ("nccl" IS RCCL on ROCm).  DTS_DIST_BACKEND=gloo exists only to rehearse the multi-rank control
+        # flow on a one-GPU box (ranks share the card; collectives staged through the host).
+        backend = os.environ.get('DTS_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
     if a.gpus != world and rank == 0 and world > 1:
         print(f'warning: --gpus {a.gpus} but WORLD_SIZE {world}', file=sys.stderr)
-    dev = torch.device('cuda', local if world > 1 else 0)
     torch.cuda.set_device(dev)
 
     from diffusion_tts_amd import init as dinit, ops
@@ -201,7 +208,7 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[dev.index]) if dist.get_backend() == 'nccl' else dist.barrier()
         torch.cuda.synchronize(dev)
 
     log(f'state resident; {nl} candidates on this rank; warmup')
@@ -217,7 +224,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     log(f'timed region: {dt:.3f}s for {a.steps} steps')
@@ -227,6 +234,10 @@ def main():
 
     # ---- per-kernel timing of the dominant kernel (implicit-GEMM conv) with HIP events on the launch stream
     roof = None
+    if not a.no_kernel_timing and rank != 0:
+        for s in range(min(2, a.steps)):           # the steps contain the reward all-gather: every rank must take part
+            one_step(a.warmup + s)
+        torch.cuda.synchronize(dev)
     if not a.no_kernel_timing and rank == 0:
         rec = []
         orig = ops.conv2d
@@ -267,8 +278,7 @@ def main():
                 'avg_launch_us': round(ms * 1e3 / len(rec), 2), 'avg_launch_gflop': round(fl / len(rec) / 1e9, 3),
                 'conv_ms_per_step': round(ms / min(2, a.steps), 2),
                 'whole_step_frac': round((value / world) * ADM_GFLOP_PER_EVAL * 1e9 / (peak * 1e12), 4)}
-    if world > 1:
-        dist.barrier()
+    barrier()
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

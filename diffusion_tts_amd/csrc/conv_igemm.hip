@@ -124,18 +124,17 @@ template <> struct Vec4<f16_t> {
   }
 };
 
-__device__ uint4 g_zero16[1];      // source of padded (out-of-image) rows
+__device__ uint4 g_zero16[512];    // 8 KiB of zeros: source of padded (out-of-image) rows; a row pointer into it is advanced
+                                   // along K like a real one (cin * element size <= 6 KiB), so no per-step select is needed
 
 // LDS-DMA through inline asm: hipcc does not count an asm memory op in its s_waitcnt bookkeeping, so it does not
 // drain the in-flight tile in front of the (non-aliasing) ds_reads of the other buffer, as it does for the builtin.
 // Completion is awaited explicitly (s_waitcnt vmcnt(0) before the barrier that publishes the tile).
 // lds_off must be wave-uniform (LDS byte address of this wave-instruction's 1 KiB destination).
 __device__ __forceinline__ void glds16(const char* g, uint32_t lds_off) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(g), "s"(lds_off)
-               : "memory");
+  // M0 carries the LDS destination; it is written in the same statement that reads it and declared clobbered (the
+  // compiler keeps nothing live in M0 in these kernels), which saves the save/restore pair per load.
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_off) : "memory", "m0");
 }
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
@@ -306,41 +305,44 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_ige
   const int ks_begin = blockIdx.y * kp.ks_per_split;
   const int ks_end = min(nk_all, ks_begin + kp.ks_per_split);
 
-  int src_pix[RB];                                     // source pixel index (or -1) for the tap being issued
+  // Issue-side addressing is incremental: per-row source pointers are rebuilt only when the tap (or the concat source)
+  // changes and otherwise just advance by one K step (one 64-bit add per load).  The per-load address arithmetic of the
+  // first version (64-bit multiply-add, select, M0 save/restore: ~14 instructions x 10 loads) was costing each wave about
+  // as many issue cycles per K step as its 48 MFMAs.
   const int schunk = (chunk ^ (r0 & 7)) * 16;          // source chunk of this lane's (linear) LDS slot
-  const char* wsrc = p_w + ((size_t)(cm0 + r0) * K) * ES + schunk;
   const char* zsrc = reinterpret_cast<const char*>(g_zero16);
+  const char* arow[RA];
+  const char* brow[RB];
   // LDS byte address of this wave's 8 rows inside each slab (wave-uniform by construction)
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const uint32_t wave_rows = __builtin_amdgcn_readfirstlane(lds_base + (tid >> 6) * 8 * 128);
 
-#define SET_TAP(tap_)                                                                                         \
+#define SET_ROWS(tap_, ci0_)                                                                                  \
   {                                                                                                           \
     const int dh_ = (p_taps == 9) ? (tap_) / 3 - 1 : 0, dw_ = (p_taps == 9) ? (tap_) % 3 - 1 : 0;             \
+    const char* xb; int cs, cofs;                                                                             \
+    if ((ci0_) < p_c1) { xb = p_x1; cs = p_c1; cofs = (ci0_); } else { xb = p_x2; cs = p_c2; cofs = (ci0_) - p_c1; } \
     _Pragma("unroll") for (int j = 0; j < RB; ++j) {                                                          \
       const int hu = (pix_hw[j] >> 16) + dh_, wu = (pix_hw[j] & 0xffff) + dw_;                                \
       const bool ok = pix_n[j] >= 0 && (unsigned)hu < (unsigned)p_hout && (unsigned)wu < (unsigned)p_wout;    \
       const int hs = p_up ? (hu >> 1) : hu, ws = p_up ? (wu >> 1) : wu;                                       \
-      src_pix[j] = ok ? pix_n[j] + hs * p_win + ws : -1;                                                      \
+      brow[j] = ok ? xb + ((size_t)(pix_n[j] + hs * p_win + ws) * cs + cofs) * ES + schunk : zsrc;            \
     }                                                                                                         \
   }
-#define ISSUE_TILE(buf_, ks_, ci0_)                                                                           \
+#define ISSUE_TILE(buf_)                                                                                      \
   {                                                                                                           \
     const uint32_t sa_ = wave_rows + (buf_) * STAGE_BYTES;                                                    \
     const uint32_t sb_ = sa_ + A_BYTES;                                                                       \
-    const char* wp = wsrc + (size_t)(ks_) * BKE * ES;                                                         \
-    _Pragma("unroll") for (int j = 0; j < RA; ++j) glds16(wp + (size_t)(SLAB * j) * K * ES, sa_ + j * SLAB * 128); \
-    const char* xb; int cs, cofs;                                                                             \
-    if ((ci0_) < p_c1) { xb = p_x1; cs = p_c1; cofs = (ci0_); } else { xb = p_x2; cs = p_c2; cofs = (ci0_) - p_c1; } \
-    _Pragma("unroll") for (int j = 0; j < RB; ++j) {                                                          \
-      const char* src = src_pix[j] >= 0 ? xb + ((size_t)src_pix[j] * cs + cofs) * ES + schunk : zsrc;         \
-      glds16(src, sb_ + j * SLAB * 128);                                                                      \
-    }                                                                                                         \
+    _Pragma("unroll") for (int j = 0; j < RA; ++j) glds16(arow[j], sa_ + j * SLAB * 128);                     \
+    _Pragma("unroll") for (int j = 0; j < RB; ++j) glds16(brow[j], sb_ + j * SLAB * 128);                     \
   }
 #define ADVANCE_K()                                                                                           \
   {                                                                                                           \
     ci0 += BKE;                                                                                               \
-    if (ci0 == p_cin) { ci0 = 0; ++tap; SET_TAP(tap); }                                                       \
+    _Pragma("unroll") for (int j = 0; j < RA; ++j) arow[j] += BKE * ES;                                       \
+    if (ci0 == p_cin) { ci0 = 0; ++tap; SET_ROWS(tap, 0); }                                                   \
+    else if (ci0 == p_c1) { SET_ROWS(tap, ci0); }                                                             \
+    else { _Pragma("unroll") for (int j = 0; j < RB; ++j) brow[j] += BKE * ES; }                              \
   }
 
   f32x4_t acc[MT][NT];
@@ -351,12 +353,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_ige
 
   // issue-side K state (tap, cin offset) runs STAGES-1 tiles ahead of the compute side
   int tap = ks_begin / steps_per_tap, ci0 = (ks_begin - tap * steps_per_tap) * BKE;
-  SET_TAP(tap);
-  ISSUE_TILE(0, ks_begin, ci0);
+#pragma unroll
+  for (int j = 0; j < RA; ++j) arow[j] = p_w + ((size_t)(cm0 + r0 + SLAB * j) * K + (size_t)ks_begin * BKE) * ES + schunk;
+  SET_ROWS(tap, ci0);
+  ISSUE_TILE(0);
   if (STAGES == 3) {
     if (ks_begin + 1 < ks_end) {
       ADVANCE_K();
-      ISSUE_TILE(1, ks_begin + 1, ci0);
+      ISSUE_TILE(1);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RA + RB) : "memory");      // tile 0 landed, tile 1 in flight
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_ige
     if (ks + STAGES - 1 < ks_end) {
       ADVANCE_K();
       const int wb = buf + STAGES - 1 >= STAGES ? buf - 1 : buf + STAGES - 1;
-      ISSUE_TILE(wb, ks + STAGES - 1, ci0);
+      ISSUE_TILE(wb);
     }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -413,6 +417,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_ige
 
   conv_epilogue<T, MT, NT>(kp, acc, cm0, pn0, (int)blockIdx.y, wm, wn, lrow, lq);
 }
+#undef SET_ROWS
+#undef ISSUE_TILE
+#undef ADVANCE_K
 
 // ---- persistent variant: each block walks work items (pixel tile x cout tile x K split) v = blockIdx.x, +gridDim.x, ...
 // and keeps ONE continuous double-buffered tile stream across them: during the last K step of an item the first tile of
@@ -451,6 +458,35 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_persist_kernel(const ConvP 
   const char* wsrc;
   int tap, ci0, ks_i;                   // K position of the tile being issued
   int i_cm0, i_pn0, i_split, i_ks_begin, i_ks_end;
+
+#define SET_TAP(tap_)                                                                                         \
+  {                                                                                                           \
+    const int dh_ = (p_taps == 9) ? (tap_) / 3 - 1 : 0, dw_ = (p_taps == 9) ? (tap_) % 3 - 1 : 0;             \
+    _Pragma("unroll") for (int j = 0; j < RB; ++j) {                                                          \
+      const int hu = (pix_hw[j] >> 16) + dh_, wu = (pix_hw[j] & 0xffff) + dw_;                                \
+      const bool ok = pix_n[j] >= 0 && (unsigned)hu < (unsigned)p_hout && (unsigned)wu < (unsigned)p_wout;    \
+      const int hs = p_up ? (hu >> 1) : hu, ws = p_up ? (wu >> 1) : wu;                                       \
+      src_pix[j] = ok ? pix_n[j] + hs * p_win + ws : -1;                                                      \
+    }                                                                                                         \
+  }
+#define ISSUE_TILE(buf_, ks_, ci0_)                                                                           \
+  {                                                                                                           \
+    const uint32_t sa_ = wave_rows + (buf_) * STAGE_BYTES;                                                    \
+    const uint32_t sb_ = sa_ + A_BYTES;                                                                       \
+    const char* wp = wsrc + (size_t)(ks_) * BKE * ES;                                                         \
+    _Pragma("unroll") for (int j = 0; j < RA; ++j) glds16(wp + (size_t)(SLAB * j) * K * ES, sa_ + j * SLAB * 128); \
+    const char* xb; int cs, cofs;                                                                             \
+    if ((ci0_) < p_c1) { xb = p_x1; cs = p_c1; cofs = (ci0_); } else { xb = p_x2; cs = p_c2; cofs = (ci0_) - p_c1; } \
+    _Pragma("unroll") for (int j = 0; j < RB; ++j) {                                                          \
+      const char* src = src_pix[j] >= 0 ? xb + ((size_t)src_pix[j] * cs + cofs) * ES + schunk : zsrc;         \
+      glds16(src, sb_ + j * SLAB * 128);                                                                      \
+    }                                                                                                         \
+  }
+#define ADVANCE_K()                                                                                           \
+  {                                                                                                           \
+    ci0 += BKE;                                                                                               \
+    if (ci0 == p_cin) { ci0 = 0; ++tap; SET_TAP(tap); }                                                       \
+  }
 
 #define P_SETUP_ITEM(v_)                                                                                      \
   {                                                                                                           \
