@@ -177,3 +177,45 @@ def test_cpu_device_is_refused(pkg, golden, manifest):
     sm = pkg['sampler']
     with pytest.raises(RuntimeError, match='GPU'):
         sm.generate_image_grid(net, None, T(golden['search_latents1']), T(golden['search_lab1']), device=torch.device('cpu'))
+
+
+def test_precomputed_noise_hooks_and_edge_sizes(pkg, golden, manifest):
+    """The `precomputed_noise` hooks of generate_image_grid (edm/main.py:114-117, 724-735, 753-755, 791-792) and the
+    degenerate search sizes N=1 / K=1, against the CPU oracle (same hooks restated there)."""
+    from helpers import oracle_net
+    from oracle import sampler as osamp, scorers as oscore
+    sm, S = pkg['sampler'], pkg['scorers']
+    cfg, sd = tiny_edm(manifest, 'adm_tiny')
+    net, onet_ = hip_net(pkg, manifest, 'adm_tiny', torch.float32), oracle_net(cfg, sd)
+    lat, lab = T(golden['search_latents2']), T(golden['search_lab2'])
+    g = torch.Generator().manual_seed(77)
+    kw = dict(seed=5, num_steps=4, S_churn=40, S_min=0.05, S_max=50, S_noise=1.003)
+
+    def both(method, params, pre):
+        o = osamp.search(onet_, lat, lab, method=method, params=dict(scorer=oscore.BrightnessOracle(), **params),
+                         precomputed_noise=pre, scale_fn=seed0_scale, **kw)
+        h = sm.generate_image_grid(net, None, lat, lab, gridw=2, gridh=1, device=torch.device(DEV),
+                                   sampling_method={'rejection': sm.SamplingMethod.REJECTION_SAMPLING,
+                                                    'eps_greedy': sm.SamplingMethod.EPS_GREEDY}[method],
+                                   sampling_params=dict(scorer=S.BrightnessScorer(), **params), precomputed_noise=pre,
+                                   scale_fn=seed0_scale, compute_dtype=torch.float32, verbose=False, **kw)
+        assert len(o['selected']) == len(h['selected'])
+        for a, b in zip(o['selected'], h['selected']):
+            assert torch.equal(a, b), (method, params)
+        assert (o['x'] - h['x'].cpu()).abs().max().item() < IMG_TOL
+        assert h['net_rows'] == onet_.evals - both.prev
+        both.prev = onet_.evals
+    both.prev = onet_.evals
+    # rejection with noise supplied for steps 0 and 2 ([B, maxN, C, H, W]; the first N are used)
+    pre = {0: torch.randn(2, 6, 3, 16, 16, generator=g, dtype=torch.float64), 2: torch.randn(2, 6, 3, 16, 16, generator=g, dtype=torch.float64)}
+    both('rejection', dict(N=3), pre)
+    # eps-greedy with a supplied pivot per step, supplied directions for step 1 and one supplied fresh sample
+    pre = {'pivot_0': torch.randn(2, 3, 16, 16, generator=g, dtype=torch.float64), 'pivot_2': torch.randn(2, 3, 16, 16, generator=g, dtype=torch.float64),
+           1: torch.randn(2, 2, 3, 3, 16, 16, generator=g, dtype=torch.float64)}
+    for k in range(2):
+        for n in range(3):
+            pre[f'fresh_3_{k}_{n}'] = torch.randn(2, 3, 16, 16, generator=g, dtype=torch.float64)
+    both('eps_greedy', dict(N=3, K=2, lambda_param=0.15, eps=0.4), pre)
+    # degenerate sizes
+    both('eps_greedy', dict(N=1, K=1, lambda_param=0.15, eps=0.4), None)
+    both('rejection', dict(N=1), None)
