@@ -245,8 +245,9 @@ def main():
 
         def timed_conv(x1, w, bias=None, **kw):
             # keep the GPU busy while the host enqueues (e0, kernel, e1): otherwise the pair brackets the host's
-            # launch latency as well and the short kernels read long (checked against rocprofv3)
-            torch.cuda._sleep(200_000)
+            # launch latency as well and the short kernels read long (checked against rocprofv3).  ~0.4 ms of spin:
+            # 200k cycles (~80 us) was not always enough for the Python-side enqueue on a slower host (151 vs 101 us).
+            torch.cuda._sleep(1_000_000)
             e0 = hev.record()
             out = orig(x1, w, bias, **kw)
             e1 = hev.record()

@@ -9,7 +9,7 @@ import torch  # noqa: F401  -- must come first: torch ships its own libamdhip64;
 #                              process two HIP runtimes (kernels would then launch on a runtime with no device context)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdts_hip.so')
+LIB_PATH = os.environ.get('DTS_LIB_PATH') or os.path.join(_HERE, 'libdts_hip.so')     # override: A/B kernel tuning only
 
 DTS_F32, DTS_BF16, DTS_F16 = 0, 1, 2
 

@@ -21,12 +21,11 @@
 // Double-buffered: tile k+1 is in flight while tile k feeds the MFMAs.
 // f32 mode uses v_mfma_f32_16x16x4_f32 (exact f32 FMA chain) = the parity path.
 #include "dts_common.h"
+#include <type_traits>
 
 namespace {
 
 thread_local bool g_stats_written = false;
-int g_persist = 0;             // DTS_CONV_PERSIST=1 enables the persistent (cross-tile prefetch) variant: measured no faster
-                               // than letting the hardware interleave two resident blocks per CU (profiles/r01_conv_variants.txt)
 
 struct ConvP {
   const char* x1; const char* x2;
@@ -248,14 +247,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
   }
 }
 
-template <typename T, int MT, int NT, int WM, int WN, int STAGES>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_igemm_kernel(const ConvP kp) {
+// PF: both k-substeps' fragments are read ahead of the first MFMA (40 more VGPRs; the second set lands while the first
+// set's MFMAs run).  Measured on one box against the read-as-you-go order: +3..11 % on the 3x3 layers, -4..8 % on the
+// short-K 1x1 layers, so the launcher picks it by kernel size.
+template <typename T, int MT, int NT, int WM, int WN, bool PF>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
   const char* const p_x1 = kp.x1; const char* const p_x2 = kp.x2; const char* const p_w = kp.w;
   const int p_c1 = kp.c1, p_c2 = kp.c2, p_cin = kp.cin, p_hin = kp.hin, p_win = kp.win, p_hout = kp.hout, p_wout = kp.wout;
   const int p_taps = kp.taps, p_up = kp.up, p_P = kp.P, p_n_ct = kp.n_ct, p_n_pt = kp.n_pt;
-  constexpr int NW = WM * WN;              // waves per block (4: two blocks per CU; 8: one block per CU, 3-stage ring)
-  static_assert(NW == 4 || NW == 8, "4 or 8 waves per block");
-  static_assert(STAGES == 2 || STAGES == 3, "2- or 3-stage LDS ring");
+  constexpr int NW = WM * WN;              // 4 waves per block, two blocks per CU (8-wave / 3-stage blocks with one block per
+  static_assert(NW == 4, "4 waves");      // CU and persistent blocks were measured slower: profiles/r01_conv_variants.txt)
+  constexpr int STAGES = 2;                // LDS ring: tile k+1 in flight while tile k feeds the MFMAs
   constexpr int SLAB = 8 * NW;             // rows staged by one wave-instruction round of the whole block
   constexpr int BM = 16 * MT * WM;         // couts per block
   constexpr int BN = 16 * NT * WN;         // pixels per block
@@ -357,17 +359,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_ige
   for (int j = 0; j < RA; ++j) arow[j] = p_w + ((size_t)(cm0 + r0 + SLAB * j) * K + (size_t)ks_begin * BKE) * ES + schunk;
   SET_ROWS(tap, ci0);
   ISSUE_TILE(0);
-  if (STAGES == 3) {
-    if (ks_begin + 1 < ks_end) {
-      ADVANCE_K();
-      ISSUE_TILE(1);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RA + RB) : "memory");      // tile 0 landed, tile 1 in flight
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const int lrow = lane & 15, lq = lane >> 4;
@@ -375,44 +367,47 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_ige
   for (int ks = ks_begin; ks < ks_end; ++ks) {
     const char* sa = smem + buf * STAGE_BYTES + (wm * 16 * MT) * 128;
     const char* sb = smem + buf * STAGE_BYTES + A_BYTES + (wn * 16 * NT) * 128;
-    uint4 fa[MT], fb[NT];
-    // fragment reads of the first k-substep go out first; the LDS-DMA issue for the tile STAGES-1 ahead (address
-    // arithmetic + M0 writes, ~400 issue cycles) then overlaps their latency instead of delaying the first MFMA
-#pragma unroll
-    for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq));
+    uint4 fa[MT], fb[NT], ga[MT], gb[NT];
+    // fragment reads go out first; the LDS-DMA issue for the next tile (address arithmetic + M0 writes) then overlaps
+    // their latency instead of delaying the first MFMA
 #pragma unroll
     for (int i = 0; i < NT; ++i) fb[i] = *reinterpret_cast<const uint4*>(sb + swz(i * 16 + lrow, lq));
+#pragma unroll
+    for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq));
+    if (PF) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) gb[i] = *reinterpret_cast<const uint4*>(sb + swz(i * 16 + lrow, lq + 4));
+#pragma unroll
+      for (int i = 0; i < MT; ++i) ga[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq + 4));
+    }
     // the buffer written here was last read in iteration ks-1; every wave has passed that iteration's barrier
-    if (ks + STAGES - 1 < ks_end) {
+    if (ks + 1 < ks_end) {
       ADVANCE_K();
-      const int wb = buf + STAGES - 1 >= STAGES ? buf - 1 : buf + STAGES - 1;
-      ISSUE_TILE(wb);
+      ISSUE_TILE(buf ^ 1);
     }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
-    __builtin_amdgcn_s_setprio(0);
+    if (!PF) {
+      __builtin_amdgcn_s_setprio(0);
 #pragma unroll
-    for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq + 4));
+      for (int i = 0; i < NT; ++i) gb[i] = *reinterpret_cast<const uint4*>(sb + swz(i * 16 + lrow, lq + 4));
 #pragma unroll
-    for (int i = 0; i < NT; ++i) fb[i] = *reinterpret_cast<const uint4*>(sb + swz(i * 16 + lrow, lq + 4));
-    __builtin_amdgcn_s_setprio(1);
+      for (int i = 0; i < MT; ++i) ga[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq + 4));
+      __builtin_amdgcn_s_setprio(1);
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
+      for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], ga[i], gb[j]);
     __builtin_amdgcn_s_setprio(0);
-    // next tile has landed (LDS-DMA completion is tracked by vmcnt; with 3 stages the tile after it stays in
-    // flight across the barrier) and this wave's LDS reads of the current tile have returned
-    if (STAGES == 3 && ks + 2 < ks_end) {
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(RA + RB) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    }
+    // next tile has landed (LDS-DMA completion is tracked by vmcnt) and this wave's LDS reads of the current tile have
+    // returned
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    buf = buf + 1 == STAGES ? 0 : buf + 1;
+    buf ^= 1;
   }
 
   conv_epilogue<T, MT, NT>(kp, acc, cm0, pn0, (int)blockIdx.y, wm, wn, lrow, lq);
@@ -420,169 +415,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 1)) void conv_ige
 #undef SET_ROWS
 #undef ISSUE_TILE
 #undef ADVANCE_K
-
-// ---- persistent variant: each block walks work items (pixel tile x cout tile x K split) v = blockIdx.x, +gridDim.x, ...
-// and keeps ONE continuous double-buffered tile stream across them: during the last K step of an item the first tile of
-// the next item is already issued, so its load latency and the item's epilogue (global reads/stores only) overlap.
-// Layers with few K steps (1x1 convs: 6-12; the 64x64 level: 27) otherwise spend a quarter to a half of each block's
-// life in an exposed prologue load and an epilogue with an idle MFMA pipe.
-template <typename T, int MT, int NT, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv_igemm_persist_kernel(const ConvP kp) {
-  const char* const p_x1 = kp.x1; const char* const p_x2 = kp.x2; const char* const p_w = kp.w;
-  const int p_c1 = kp.c1, p_c2 = kp.c2, p_cin = kp.cin, p_hin = kp.hin, p_win = kp.win, p_hout = kp.hout, p_wout = kp.wout;
-  const int p_taps = kp.taps, p_up = kp.up, p_P = kp.P, p_n_ct = kp.n_ct, p_n_pt = kp.n_pt;
-  static_assert(WM * WN == 4, "4 waves per block");
-  constexpr int SLAB = 32;
-  constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
-  constexpr int EPV = ET<T>::EPV, BKE = 8 * EPV, ES = 16 / EPV;
-  constexpr int RA = BM / SLAB, RB = BN / SLAB;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int nblk = p_n_ct * p_n_pt;
-  const int total = nblk * kp.splits;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid % WM, wn = wid / WM;
-  const int chunk = tid & 7, r0 = tid >> 3;
-  const int lrow = lane & 15, lq = lane >> 4;
-  const int K = p_taps * p_cin;
-  const int steps_per_tap = p_cin / BKE;
-  const int nk_all = p_taps * steps_per_tap;
-  const int schunk = (chunk ^ (r0 & 7)) * 16;
-  const char* zsrc = reinterpret_cast<const char*>(g_zero16);
-  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const uint32_t wave_rows = __builtin_amdgcn_readfirstlane(lds_base + (tid >> 6) * 8 * 128);
-
-  // issue-side state (runs one tile ahead of the compute side, possibly already in the next work item)
-  int pix_n[RB], pix_hw[RB], src_pix[RB];
-  const char* wsrc;
-  int tap, ci0, ks_i;                   // K position of the tile being issued
-  int i_cm0, i_pn0, i_split, i_ks_begin, i_ks_end;
-
-#define SET_TAP(tap_)                                                                                         \
-  {                                                                                                           \
-    const int dh_ = (p_taps == 9) ? (tap_) / 3 - 1 : 0, dw_ = (p_taps == 9) ? (tap_) % 3 - 1 : 0;             \
-    _Pragma("unroll") for (int j = 0; j < RB; ++j) {                                                          \
-      const int hu = (pix_hw[j] >> 16) + dh_, wu = (pix_hw[j] & 0xffff) + dw_;                                \
-      const bool ok = pix_n[j] >= 0 && (unsigned)hu < (unsigned)p_hout && (unsigned)wu < (unsigned)p_wout;    \
-      const int hs = p_up ? (hu >> 1) : hu, ws = p_up ? (wu >> 1) : wu;                                       \
-      src_pix[j] = ok ? pix_n[j] + hs * p_win + ws : -1;                                                      \
-    }                                                                                                         \
-  }
-#define ISSUE_TILE(buf_, ks_, ci0_)                                                                           \
-  {                                                                                                           \
-    const uint32_t sa_ = wave_rows + (buf_) * STAGE_BYTES;                                                    \
-    const uint32_t sb_ = sa_ + A_BYTES;                                                                       \
-    const char* wp = wsrc + (size_t)(ks_) * BKE * ES;                                                         \
-    _Pragma("unroll") for (int j = 0; j < RA; ++j) glds16(wp + (size_t)(SLAB * j) * K * ES, sa_ + j * SLAB * 128); \
-    const char* xb; int cs, cofs;                                                                             \
-    if ((ci0_) < p_c1) { xb = p_x1; cs = p_c1; cofs = (ci0_); } else { xb = p_x2; cs = p_c2; cofs = (ci0_) - p_c1; } \
-    _Pragma("unroll") for (int j = 0; j < RB; ++j) {                                                          \
-      const char* src = src_pix[j] >= 0 ? xb + ((size_t)src_pix[j] * cs + cofs) * ES + schunk : zsrc;         \
-      glds16(src, sb_ + j * SLAB * 128);                                                                      \
-    }                                                                                                         \
-  }
-#define ADVANCE_K()                                                                                           \
-  {                                                                                                           \
-    ci0 += BKE;                                                                                               \
-    if (ci0 == p_cin) { ci0 = 0; ++tap; SET_TAP(tap); }                                                       \
-  }
-
-#define P_SETUP_ITEM(v_)                                                                                      \
-  {                                                                                                           \
-    const int sp_ = (v_) / nblk;                                                                              \
-    int t_ = (v_) - sp_ * nblk;                                                                               \
-    {                                                                                                         \
-      const int q = nblk >> 3, r = nblk & 7, xcd = t_ & 7, j = t_ >> 3;                                       \
-      t_ = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;                                       \
-    }                                                                                                         \
-    const int ct_ = t_ % p_n_ct, pt_ = t_ / p_n_ct;                                                           \
-    i_cm0 = ct_ * BM; i_pn0 = pt_ * BN; i_split = sp_;                                                        \
-    i_ks_begin = sp_ * kp.ks_per_split;                                                                       \
-    i_ks_end = min(nk_all, i_ks_begin + kp.ks_per_split);                                                     \
-    _Pragma("unroll") for (int j = 0; j < RB; ++j) {                                                          \
-      const int pp = i_pn0 + r0 + SLAB * j;                                                                   \
-      if (pp < p_P) {                                                                                         \
-        const int hw = p_hout * p_wout;                                                                       \
-        const int n = pp / hw, rem = pp - n * hw;                                                             \
-        const int ho = rem / p_wout, wo = rem - ho * p_wout;                                                  \
-        pix_n[j] = n * p_hin * p_win;                                                                         \
-        pix_hw[j] = (ho << 16) | wo;                                                                          \
-      } else {                                                                                                \
-        pix_n[j] = -1;                                                                                        \
-        pix_hw[j] = 0;                                                                                        \
-      }                                                                                                       \
-    }                                                                                                         \
-    wsrc = p_w + ((size_t)(i_cm0 + r0) * K) * ES + schunk;                                                    \
-    ks_i = i_ks_begin;                                                                                        \
-    tap = ks_i / steps_per_tap;                                                                               \
-    ci0 = (ks_i - tap * steps_per_tap) * BKE;                                                                 \
-    SET_TAP(tap);                                                                                             \
-  }
-
-  int v = blockIdx.x;
-  if (v >= total) return;
-  P_SETUP_ITEM(v);
-  ISSUE_TILE(0, ks_i, ci0);
-  int buf = 0;
-  f32x4_t acc[MT][NT];
-  while (true) {
-    // compute-side description of item v (the issue side still points at it: nothing beyond its first tile is issued)
-    const int c_cm0 = i_cm0, c_pn0 = i_pn0, c_split = i_split, nsteps = i_ks_end - i_ks_begin;
-    const int vnext = v + gridDim.x;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int s_ = 0; s_ < nsteps; ++s_) {
-      const char* sa = smem + buf * STAGE_BYTES + (wm * 16 * MT) * 128;
-      const char* sb = smem + buf * STAGE_BYTES + A_BYTES + (wn * 16 * NT) * 128;
-      uint4 fa[MT], fb[NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq));
-#pragma unroll
-      for (int i = 0; i < NT; ++i) fb[i] = *reinterpret_cast<const uint4*>(sb + swz(i * 16 + lrow, lq));
-      // next tile of the stream into the other buffer (last read one step ago; every wave has passed that barrier)
-      if (s_ + 1 < nsteps) {
-        ++ks_i;
-        ADVANCE_K();
-        ISSUE_TILE(buf ^ 1, ks_i, ci0);
-      } else if (vnext < total) {
-        P_SETUP_ITEM(vnext);
-        ISSUE_TILE(buf ^ 1, ks_i, ci0);
-      }
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
-      __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-      for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq + 4));
-#pragma unroll
-      for (int i = 0; i < NT; ++i) fb[i] = *reinterpret_cast<const uint4*>(sb + swz(i * 16 + lrow, lq + 4));
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
-      __builtin_amdgcn_s_setprio(0);
-      if (s_ + 1 < nsteps) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the next item's first tile stays in flight over the epilogue
-      }
-      buf ^= 1;
-    }
-    conv_epilogue<T, MT, NT>(kp, acc, c_cm0, c_pn0, c_split, wm, wn, lrow, lq);
-    if (vnext >= total) break;
-    v = vnext;
-  }
-#undef P_SETUP_ITEM
-}
 
 // split-K second pass: fixed-order sum of the f32 slabs + the conv epilogue
 template <typename T>
@@ -618,7 +450,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvP kp)
   }
 }
 
-template <typename T, int MT, int NT, int WM, int WN, int STAGES>
+template <typename T, int MT, int NT, int WM, int WN, bool PF>
 int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes) {
   constexpr int NW = WM * WN;
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
@@ -629,7 +461,7 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes) {
   const int nblk = q.n_ct * q.n_pt;
   const int nk = p.taps * (p.cin / BKE);
   // split-K when the tile grid cannot fill the chip (256 CUs x resident blocks per CU)
-  const int slots = NW == 4 ? 512 : 256;
+  const int slots = 512;                                     // 256 CUs x 2 resident blocks
   int splits = 1;
   if (ws != nullptr && nblk < (slots * 3) / 4 && nk >= 16) {
     splits = (slots + nblk - 1) / nblk;
@@ -644,26 +476,14 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes) {
   q.partial = ws;
   if (splits > 1 || NT != 4) q.stats = nullptr;              // the split-K reduce pass does not produce statistics
   g_stats_written = q.stats != nullptr;
-  const size_t lds = (size_t)STAGES * (BM + BN) * 128;
+  const size_t lds = (size_t)2 * (BM + BN) * 128;
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, MT, NT, WM, WN, STAGES>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, MT, NT, WM, WN, PF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  if (NW == 4 && STAGES == 2 && g_persist && nblk * splits > slots) {
-    if constexpr (NW == 4 && STAGES == 2) {
-      static bool attr2_done = false;
-      if (!attr2_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_persist_kernel<T, MT, NT, WM, WN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr2_done = true;
-      }
-      hipLaunchKernelGGL((conv_igemm_persist_kernel<T, MT, NT, WM, WN>), dim3(slots), dim3(256), lds, st, q);
-    }
-  } else {
-    hipLaunchKernelGGL((conv_igemm_kernel<T, MT, NT, WM, WN, STAGES>), dim3(nblk, splits), dim3(64 * NW), lds, st, q);
-  }
+  hipLaunchKernelGGL((conv_igemm_kernel<T, MT, NT, WM, WN, PF>), dim3(nblk, splits), dim3(64 * NW), lds, st, q);
   DTS_CHECK_LAUNCH("dts_conv2d");
   if (splits > 1) {
     long long g = ((long long)p.P * (p.cout / 4) + 255) / 256;
@@ -675,30 +495,28 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes) {
 }
 
 int g_tile_override = -1;      // DTS_CONV_TILE=64|128|192 (tuning aid; only honoured when it divides cout)
-int g_impl_override = -1;      // DTS_CONV_IMPL=4|8: 4-wave 2-stage blocks (2 per CU) or 8-wave 3-stage blocks (1 per CU)
+
+template <typename T, bool PF>
+int conv_dispatch_tile(const ConvP& p, int tile, hipStream_t st, float* ws, long long ws_bytes) {
+  switch (tile) {
+    case 192: return launch_conv<T, 6, 4, 2, 2, PF>(p, st, ws, ws_bytes);
+    case 128: return launch_conv<T, 4, 4, 2, 2, PF>(p, st, ws, ws_bytes);
+    default: return launch_conv<T, 4, 4, 1, 4, PF>(p, st, ws, ws_bytes);
+  }
+}
 
 template <typename T>
 int conv_dispatch(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes) {
   if (g_tile_override < 0) {
     const char* e = getenv("DTS_CONV_TILE");
     g_tile_override = e ? atoi(e) : 0;
-    const char* f = getenv("DTS_CONV_IMPL");
-    g_impl_override = f ? atoi(f) : 0;
-    const char* pz = getenv("DTS_CONV_PERSIST");
-    if (pz) g_persist = atoi(pz);
   }
   int tile = (p.cout % 192 == 0) ? 192 : (p.cout % 128 == 0 ? 128 : 64);    // measured: tools/conv_bench.py
   if (g_tile_override > 0 && p.cout % g_tile_override == 0) tile = g_tile_override;
-  const int impl = g_impl_override == 8 ? 8 : 4;
-  if (impl == 8 && tile != 64) {
-    if (tile == 192) return launch_conv<T, 6, 3, 2, 4, 3>(p, st, ws, ws_bytes);      // 192 x 192, 144 KB LDS
-    return launch_conv<T, 4, 4, 2, 4, 3>(p, st, ws, ws_bytes);                       // 128 x 256, 144 KB LDS
-  }
-  switch (tile) {
-    case 192: return launch_conv<T, 6, 4, 2, 2, 2>(p, st, ws, ws_bytes);
-    case 128: return launch_conv<T, 4, 4, 2, 2, 2>(p, st, ws, ws_bytes);
-    default: return launch_conv<T, 4, 4, 1, 4, 2>(p, st, ws, ws_bytes);
-  }
+  // fragment prefetch pays on the long K loops of the 3x3 layers; f32 (parity mode) keeps the lean order: its 192-cout
+  // tile is already at the 256-VGPR limit
+  if (p.taps == 9 && !std::is_same<T, float>::value) return conv_dispatch_tile<T, true>(p, tile, st, ws, ws_bytes);
+  return conv_dispatch_tile<T, false>(p, tile, st, ws, ws_bytes);
 }
 
 }  // namespace

@@ -76,6 +76,7 @@ class _Loop:
         self.S_churn, self.S_min, self.S_max, self.S_noise = S_churn, S_min, S_max, S_noise
         self.scale_fn, self.shards = scale_fn, shards
         self.rewards, self.selected = [], []
+        self.record_noises, self.best_noises = False, {}
         self.reuse_winner = False
 
     def up(self, t, dtype=None):
@@ -236,6 +237,8 @@ def _eps_greedy(L: _Loop, t_steps, x_next, labels, p, pre):
                 rows = [ops.candidate_noise(pivot[b:b + 1].contiguous(), L.up(g_w[b:b + 1]), L.up(mode_t[j:j + 1]),
                                             L.up(scale_t[j:j + 1])) for b, j in enumerate(bl)]
                 pivot = torch.cat(rows, dim=0)
+            if L.record_noises:                                                        # best_noises_this_timestep (:741, :854)
+                L.best_noises.setdefault(i, []).append(pivot.cpu())
             if L.reuse_winner and k == K - 1:
                 # the step the reference recomputes at :860 for the final pivot IS the winner's row of this iteration
                 rows = []
@@ -372,10 +375,11 @@ def generate_image_grid(
     sampling_params: Optional[Dict[str, Any]] = None,
     precomputed_noise: Optional[Dict[Any, torch.Tensor]] = None,
     *, scale_fn: Callable[[int, int, int], float] = builtin_scale, compute_dtype=torch.bfloat16, verbose=True,
-    reuse_winner: Optional[bool] = None,
+    reuse_winner: Optional[bool] = None, record_noises: bool = False,
 ):
     """Same positional/keyword surface as edm/main.py:47-55.  Keyword-only extras: `scale_fn` (the hash-derived step
-    table, edm/main.py:776), `compute_dtype` (float32 = parity mode), `verbose`, `reuse_winner` (see below).  Writes the PNG grid like the
+    table, edm/main.py:776), `compute_dtype` (float32 = parity mode), `verbose`, `reuse_winner` (see below), `record_noises`
+    (keep the per-iteration winning noises for `dump_noise_trajectory`; costs one D2H copy per iteration).  Writes the PNG grid like the
     reference when `dest_path` is not None and additionally returns a dict with the final state and the search trace."""
     device = torch.device(device)
     if device.type != 'cuda':
@@ -393,6 +397,7 @@ def generate_image_grid(
     # eps-greedy: the reference re-runs step() at batch 1 for the final pivot of each timestep (edm/main.py:860) although
     # that row was just computed in the last candidate batch.  Throughput modes reuse it; parity mode recomputes.
     L.reuse_winner = (compute_dtype != torch.float32) if reuse_winner is None else bool(reuse_winner)
+    L.record_noises = bool(record_noises)
     x0 = (latents.to(torch.float64).cpu() * t_steps[0]).to(device).contiguous()       # edm/main.py:99
     labels = None if class_labels is None else class_labels.to(device, torch.float32).contiguous()
     evals0 = getattr(net, 'evals', 0)
@@ -414,4 +419,20 @@ def generate_image_grid(
         print('Done.')
     return dict(x=x_next, image=img_cpu, final_scores=scores.cpu(), avg_score=avg_score, t_steps=t_steps,
                 rewards=L.rewards, selected=L.selected, net_rows=getattr(net, 'evals', 0) - evals0,
-                collectives=shards.collectives)
+                collectives=shards.collectives, best_noises={i: torch.stack(v) for i, v in L.best_noises.items()})
+
+
+def dump_noise_trajectory(result, directory='.'):
+    """Write the winning noise of every local-search iteration in the format the reference's diffusion-map tool loads
+    (edm/dmap.py:16-24): `all_timestep_noises.pkl` = {timestep index: Tensor[K, B, C, H, W]} and `t_steps.pkl`.  The
+    reference's loop collects exactly this list (edm/main.py:739-741, 853-854) but never writes it; `result` is the
+    dict returned by `generate_image_grid(..., record_noises=True)`."""
+    import os
+    import pickle
+    if not result.get('best_noises'):
+        raise ValueError('no noise trajectory recorded: call generate_image_grid(..., record_noises=True) with a local-search method')
+    os.makedirs(directory, exist_ok=True)
+    with open(os.path.join(directory, 'all_timestep_noises.pkl'), 'wb') as f:
+        pickle.dump({int(i): v.cpu() for i, v in result['best_noises'].items()}, f)
+    with open(os.path.join(directory, 't_steps.pkl'), 'wb') as f:
+        pickle.dump(result['t_steps'].cpu(), f)

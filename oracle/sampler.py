@@ -131,6 +131,7 @@ def _eps_greedy(ctx, t_steps, x_next, labels, p, pre, trace, scale_fn):
             trace['selected'].append(best.clone())
             nb = all_noises.reshape(N, B, *all_noises.shape[1:])
             pivot = torch.stack([nb[j, b] for b, j in enumerate(best)])
+            trace['best_noises'].setdefault(i, []).append(pivot.clone())       # best_noises_this_timestep (:741, :854)
         x_next, _ = ctx.heun_step(x_cur, t_cur, t_next, i, pivot, labels)
     return x_next
 
@@ -242,9 +243,10 @@ def search(net, latents, class_labels, *, method='naive', params: Optional[Dict[
     t_steps = sigma_schedule(net, num_steps, sigma_min, sigma_max, rho)
     ctx = _Ctx(net, num_steps, S_churn, S_min, S_max, S_noise)
     x0 = latents.to(torch.float64) * t_steps[0]
-    trace = dict(rewards=[], selected=[])
+    trace = dict(rewards=[], selected=[], best_noises={})
     x_next = _METHODS[method](ctx, t_steps, x0, class_labels, p, precomputed_noise, trace, scale_fn)
     image = to_uint8(x_next)
     scores = p.scorer(image.clone(), class_labels, _zero_ts(image.shape[0]))
     return dict(x=x_next, image=image, final_scores=scores, avg_score=scores.mean().item(),
-                t_steps=t_steps, rewards=trace['rewards'], selected=trace['selected'])
+                t_steps=t_steps, rewards=trace['rewards'], selected=trace['selected'],
+                best_noises={i: torch.stack(v) for i, v in trace['best_noises'].items()})

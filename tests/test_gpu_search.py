@@ -4,6 +4,7 @@ indices must equal the reference's, final images within 1e-3 abs as BASELINE.jso
 modes (bounded deviation, reported)."""
 import numpy as np
 import pytest
+import os
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -198,10 +199,15 @@ def test_precomputed_noise_hooks_and_edge_sizes(pkg, golden, manifest):
                                    sampling_method={'rejection': sm.SamplingMethod.REJECTION_SAMPLING,
                                                     'eps_greedy': sm.SamplingMethod.EPS_GREEDY}[method],
                                    sampling_params=dict(scorer=S.BrightnessScorer(), **params), precomputed_noise=pre,
-                                   scale_fn=seed0_scale, compute_dtype=torch.float32, verbose=False, **kw)
+                                   scale_fn=seed0_scale, compute_dtype=torch.float32, verbose=False, record_noises=True, **kw)
         assert len(o['selected']) == len(h['selected'])
         for a, b in zip(o['selected'], h['selected']):
             assert torch.equal(a, b), (method, params)
+        assert set(o['best_noises']) == set(h['best_noises'])                 # noise trajectory (edm/main.py:741, 854)
+        for i in o['best_noises']:
+            assert o['best_noises'][i].shape == h['best_noises'][i].shape == (params.get('K', 0), 2, 3, 16, 16)
+            assert (o['best_noises'][i] - h['best_noises'][i]).abs().max().item() < 1e-12
+        both.last = h
         assert (o['x'] - h['x'].cpu()).abs().max().item() < IMG_TOL
         assert h['net_rows'] == onet_.evals - both.prev
         both.prev = onet_.evals
@@ -216,6 +222,12 @@ def test_precomputed_noise_hooks_and_edge_sizes(pkg, golden, manifest):
         for n in range(3):
             pre[f'fresh_3_{k}_{n}'] = torch.randn(2, 3, 16, 16, generator=g, dtype=torch.float64)
     both('eps_greedy', dict(N=3, K=2, lambda_param=0.15, eps=0.4), pre)
+    import pickle, tempfile
+    with tempfile.TemporaryDirectory() as d:                                   # the files edm/dmap.py:16-24 loads
+        sm.dump_noise_trajectory(both.last, d)
+        noises = pickle.load(open(os.path.join(d, 'all_timestep_noises.pkl'), 'rb'))
+        ts = pickle.load(open(os.path.join(d, 't_steps.pkl'), 'rb'))
+        assert sorted(noises) == [0, 1, 2, 3] and noises[0].shape == (2, 2, 3, 16, 16) and ts.shape == (5,)
     # degenerate sizes
     both('eps_greedy', dict(N=1, K=1, lambda_param=0.15, eps=0.4), None)
     both('rejection', dict(N=1), None)
