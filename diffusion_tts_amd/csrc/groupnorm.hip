@@ -134,6 +134,60 @@ __global__ __launch_bounds__(64) void gn_coef_strips_kernel(const float* __restr
   }
 }
 
+// SiLU: f32 (parity mode) keeps the exact division of the reference's x * sigmoid(x); for bf16/f16 outputs the quotient goes
+// through v_rcp_f32 (1 ulp, far below the storage rounding) -- the IEEE division sequence made the apply pass VALU-bound.
+template <typename T> __device__ __forceinline__ float silu_t(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+template <> __device__ __forceinline__ float silu_t<float>(float x) { return silu_f(x); }
+
+// Apply pass, row form: a block works on a pixel range of ONE sample and every thread keeps ONE 16-byte channel chunk, so
+// its (a,b) coefficients are loaded once and the loop body is load -> fma/SiLU -> store with no index arithmetic (the
+// grid-stride form below spends more VALU cycles on 64-bit div/mod per element than on the SiLU).  blockDim = k * nchunk.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_rows_kernel(const T* __restrict__ x1, int c1, const T* __restrict__ x2, int c2,
+                                                             const float* __restrict__ coef, T* __restrict__ out, int hw, int ppb,
+                                                             int silu) {
+  constexpr int EPV = ET<T>::EPV;
+  const int C = c1 + c2, nchunk = C / EPV;
+  const int k = blockDim.x / nchunk;
+  const int pr = threadIdx.x / nchunk, chunk = threadIdx.x - pr * nchunk;
+  const int n = blockIdx.y, c0 = chunk * EPV;
+  float A[EPV], B[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; e += 2) {
+    const float4 q = *reinterpret_cast<const float4*>(coef + ((size_t)n * C + c0 + e) * 2);
+    A[e] = q.x; B[e] = q.y; A[e + 1] = q.z; B[e + 1] = q.w;
+  }
+  const T* src; int cs;
+  if (c0 < c1) { src = x1 + (size_t)n * hw * c1 + c0; cs = c1; } else { src = x2 + (size_t)n * hw * c2 + (c0 - c1); cs = c2; }
+  T* dst = out + (size_t)n * hw * C + c0;
+  const int p_begin = blockIdx.x * ppb, p_end = min(hw, p_begin + ppb);
+  int p = p_begin + pr;
+  // two independent pixels per trip keep two loads in flight per thread
+  for (; p + k < p_end; p += 2 * k) {
+    const uint4 v0 = *reinterpret_cast<const uint4*>(src + (size_t)p * cs);
+    const uint4 v1 = *reinterpret_cast<const uint4*>(src + (size_t)(p + k) * cs);
+    float f0[EPV], f1[EPV];
+    unpack16<T>(v0, f0);
+    unpack16<T>(v1, f1);
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      const float y0 = f0[e] * A[e] + B[e], y1 = f1[e] * A[e] + B[e];
+      f0[e] = silu ? silu_t<T>(y0) : y0;
+      f1[e] = silu ? silu_t<T>(y1) : y1;
+    }
+    *reinterpret_cast<uint4*>(dst + (size_t)p * C) = pack16<T>(f0);
+    *reinterpret_cast<uint4*>(dst + (size_t)(p + k) * C) = pack16<T>(f1);
+  }
+  if (p < p_end) {
+    const uint4 v0 = *reinterpret_cast<const uint4*>(src + (size_t)p * cs);
+    float f0[EPV];
+    unpack16<T>(v0, f0);
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) { const float y0 = f0[e] * A[e] + B[e]; f0[e] = silu ? silu_t<T>(y0) : y0; }
+    *reinterpret_cast<uint4*>(dst + (size_t)p * C) = pack16<T>(f0);
+  }
+}
+
 template <typename T, bool POOL>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1, int c1, const T* __restrict__ x2, int c2,
                                                         const float* __restrict__ coef, T* __restrict__ out,
@@ -163,7 +217,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1,
       float f[EPV];
       unpack16<T>(v, f);
 #pragma unroll
-      for (int e = 0; e < EPV; ++e) { const float y = f[e] * A[e] + B[e]; r[e] = silu ? silu_f(y) : y; }
+      for (int e = 0; e < EPV; ++e) { const float y = f[e] * A[e] + B[e]; r[e] = silu ? silu_t<T>(y) : y; }
     } else {
 #pragma unroll
       for (int e = 0; e < EPV; ++e) r[e] = 0.f;
@@ -175,7 +229,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1,
           float f[EPV];
           unpack16<T>(v, f);
 #pragma unroll
-          for (int e = 0; e < EPV; ++e) { const float y = f[e] * A[e] + B[e]; r[e] += 0.25f * (silu ? silu_f(y) : y); }
+          for (int e = 0; e < EPV; ++e) { const float y = f[e] * A[e] + B[e]; r[e] += 0.25f * (silu ? silu_t<T>(y) : y); }
         }
     }
     *reinterpret_cast<uint4*>(out + (((size_t)n * ho + yo) * wo + xo) * C + c0) = pack16<T>(r);
@@ -255,7 +309,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const T* __restrict__ x1,
     Pair<T>::load(src, a, b);
     a = a * sAB[0][cl] + sAB[1][cl];
     b = b * sAB[0][cl + 1] + sAB[1][cl + 1];
-    if (silu) { a = silu_f(a); b = silu_f(b); }
+    if (silu) { a = silu_t<T>(a); b = silu_t<T>(b); }
     Pair<T>::store(out + ((size_t)n * hw + p) * C + c, a, b);
   }
 }
@@ -374,7 +428,13 @@ extern "C" int dts_gn_apply(const void* x1, int c1, const void* x2, int c2, int 
     if (pool)
       hipLaunchKernelGGL((gn_apply_kernel<T, true>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x1, c1, (const T*)x2,
                          c2, coef, (T*)out, n, h, w, silu);
-    else
+    else if (C / epv <= 256 && n <= 65535) {
+      const int nchunk = C / epv, k = 256 / nchunk, hw = h * w;
+      long long ppb = ((long long)n * hw + 4095) / 4096;              // ~4096 blocks in all
+      ppb = ((ppb + 2 * k - 1) / (2 * k)) * (2 * k);                    // whole 2-pixel trips for every thread
+      hipLaunchKernelGGL((gn_apply_rows_kernel<T>), dim3((unsigned)((hw + ppb - 1) / ppb), n), dim3(k * nchunk), 0, st, (const T*)x1, c1,
+                         (const T*)x2, c2, coef, (T*)out, hw, (int)ppb, silu);
+    } else
       hipLaunchKernelGGL((gn_apply_kernel<T, false>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x1, c1, (const T*)x2,
                          c2, coef, (T*)out, n, h, w, silu);
     DTS_CHECK_LAUNCH("dts_gn_apply");

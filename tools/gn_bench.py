@@ -24,5 +24,7 @@ for name, r, c in [('L0', 64, 192), ('L0cat', 64, 384), ('L1', 32, 384), ('L1cat
         t_fused = timeit(lambda: ops.group_norm(x, 32, 1e-5, g, b, scale_shift=ss, path='fused'))
     except Exception as e:
         t_fused = float('nan')
+    coef = torch.randn(n, c, 2, device='cuda')
+    t_apply = timeit(lambda: ops.gn_apply(x, coef, silu=True))
     mb = x.numel() * 2 / 1e6
-    print(f'{name:6s} {mb:7.1f} MB  split {t_split:8.1f} us   fused {t_fused:8.1f} us', flush=True)
+    print(f'{name:6s} {mb:7.1f} MB  split {t_split:8.1f} us   fused {t_fused:8.1f} us   apply only {t_apply:8.1f} us = {2 * mb / t_apply:6.2f} TB/s', flush=True)
