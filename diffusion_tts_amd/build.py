@@ -10,6 +10,9 @@ LIB = os.path.join(HERE, 'libdts_hip.so')
 SOURCES = ['conv_igemm.hip', 'conv_small.hip', 'groupnorm.hip', 'attention.hip', 'elementwise.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+# per-source extras.  attention: keep the MFMA accumulators in VGPRs -- the online-softmax rescale reads and rewrites them
+# every key tile, and with the default AGPR form hipcc emitted 80 v_accvgpr_read/write per tile (a quarter of the loop's VALU).
+EXTRA = {'attention.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1']}
 
 
 def _newer(a, b):
@@ -24,7 +27,7 @@ def build(force=False, verbose=False):
         o = os.path.join(CSRC, src.replace('.hip', '.o'))
         objs.append(o)
         if force or _newer(s, o) or any(_newer(h, o) for h in hdrs):
-            jobs.append([HIPCC, *FLAGS, '-c', s, '-o', o])
+            jobs.append([HIPCC, *FLAGS, *EXTRA.get(src, []), '-c', s, '-o', o])
 
     def run(cmd):
         if verbose:

@@ -139,9 +139,9 @@ __device__ __forceinline__ void glds16(const char* g, uint32_t lds_off) {
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
 // ---- epilogue of one (cout tile, pixel tile[, K split]): lane holds couts co..co+3 of pixel pp for each (mt, nt)
-template <typename T, int MT, int NT>
+template <typename T, int MT, int NT, int BM, int BN>
 __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT][NT], int cm0, int pn0, int split, int wm, int wn,
-                                              int lrow, int lq) {
+                                              int lrow, int lq, char* smem) {
   const int p_P = kp.P, p_cout = kp.cout, p_hout = kp.hout, p_wout = kp.wout;
   // ---- epilogue: lane holds couts co..co+3 of pixel pp for each (mt, nt): one 4-element vector load/store
   if (kp.splits > 1) {
@@ -189,6 +189,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
         if (ppv[nt] >= 0) rv[mt][nt] = *reinterpret_cast<const V4*>(res + (size_t)ppv[nt] * p_cout + co_);
     }
   }
+  // 16-bit outputs leave through the (now idle) LDS tile ring: the accumulator layout gives each lane 4 couts of one pixel,
+  // i.e. 8-byte stores scattered over 16 pixel rows per instruction, and a timing-only build without the epilogue showed
+  // those stores costing a quarter of the whole conv time (2x on the 1x1 layers).  Transposed through LDS, every lane
+  // stores 16 contiguous bytes and a wave-instruction covers 1 KiB of whole output rows.
+  constexpr bool VIA_LDS = sizeof(T) == 2;
+  constexpr int ROWP = BM * 2 + 16;                    // LDS row pitch of the staged tile (pixel-major), bytes
+  static_assert(!VIA_LDS || BN * ROWP <= 2 * (BM + BN) * 128, "staged tile must fit the ring");
   const bool want_stats = NT == 4 && kp.stats != nullptr;
   float* sp = want_stats ? kp.stats + ((size_t)((pn0 + wn * 64) >> 6) * p_cout) * 2 : nullptr;
 #pragma unroll
@@ -222,7 +229,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] *= kp.out_scale;
       const V4 pk = Vec4<T>::pack(v);
-      *reinterpret_cast<V4*>(out + (size_t)ppv[nt] * p_cout + co) = pk;
+      if constexpr (VIA_LDS)
+        *reinterpret_cast<V4*>(smem + (wn * 16 * NT + nt * 16 + lrow) * ROWP + (wm * 16 * MT + mt * 16 + lq * 4) * 2) = pk;
+      else
+        *reinterpret_cast<V4*>(out + (size_t)ppv[nt] * p_cout + co) = pk;
       if (want_stats) {                                // moments of the values as stored (rounded to T)
         float f[4];
         Vec4<T>::unpack(pk, f);
@@ -243,6 +253,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
         d[0] = make_float4(ss4[0], sq4[0], ss4[1], sq4[1]);
         d[1] = make_float4(ss4[2], sq4[2], ss4[3], sq4[3]);
       }
+    }
+  }
+  if constexpr (VIA_LDS) {
+    __syncthreads();
+    constexpr int CPR = BM / 8;                          // 16-byte chunks per staged row
+    char* outb = kp.out + ((size_t)pn0 * p_cout + cm0) * 2;
+    const int rows = min(BN, p_P - pn0);
+#pragma unroll 4
+    for (int t = threadIdx.x; t < rows * CPR; t += 256) {
+      const int row = t / CPR, c = t - row * CPR;
+      *reinterpret_cast<uint4*>(outb + (size_t)row * p_cout * 2 + c * 16) = *reinterpret_cast<const uint4*>(smem + row * ROWP + c * 16);
     }
   }
 }
@@ -410,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
     buf ^= 1;
   }
 
-  conv_epilogue<T, MT, NT>(kp, acc, cm0, pn0, (int)blockIdx.y, wm, wn, lrow, lq);
+  conv_epilogue<T, MT, NT, BM, BN>(kp, acc, cm0, pn0, (int)blockIdx.y, wm, wn, lrow, lq, smem);
 }
 #undef SET_ROWS
 #undef ISSUE_TILE
