@@ -138,6 +138,114 @@ __device__ __forceinline__ void glds16(const char* g, uint32_t lds_off) {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
+// ---- epilogue fast path: 16-bit output, whole pixel tile inside the image batch (always, for the U-Net levels at the batch sizes
+// of the search loop).  No per-lane predication, every global/LDS address is one base per nt plus compile-time offsets:
+// the generic epilogue below executes ~1.5k instructions per wave (a predicated branch per access, a 64-bit address per
+// vector), which in-kernel stamps put at 9k cycles per block -- as long as 4 K steps -- before the first byte is stored.
+// Arithmetic and its order are the generic path's: ((acc + bias) + bias_nc + residual) * out_scale, rounded once.
+template <typename T, int MT, int NT, int BM, int BN>
+__device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&acc)[MT][NT], int cm0, int pn0, int wm, int wn, int lrow,
+                                                   int lq, char* smem) {
+  using V4 = typename Vec4<T>::type;
+  constexpr int ROWP = BM * 2 + 16;
+  const int p_cout = kp.cout;
+  const int prow0 = wn * 16 * NT + lrow;                 // tile-local pixel of nt = 0
+  const int col0 = wm * 16 * MT + lq * 4;                // tile-local cout of mt = 0
+  const T* __restrict__ res = reinterpret_cast<const T*>(kp.residual);
+  const T* __restrict__ bnc = reinterpret_cast<const T*>(kp.bias_nc);
+  float4 bv[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) bv[mt] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (kp.bias) {
+    const float* bp = kp.bias + cm0 + col0;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) bv[mt] = *reinterpret_cast<const float4*>(bp + mt * 16);
+  }
+  V4 rv[MT][NT];
+  if (res) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const T* rp = res + (size_t)(pn0 + prow0 + nt * 16) * p_cout + cm0 + col0;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) rv[mt][nt] = *reinterpret_cast<const V4*>(rp + mt * 16);
+    }
+  }
+  const T* np[NT];
+  if (bnc) {
+    const int hw = kp.hout * kp.wout;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) np[nt] = bnc + (size_t)((pn0 + prow0 + nt * 16) / hw) * kp.ld_bias_nc + cm0 + col0;
+  }
+  const bool want_stats = NT == 4 && kp.stats != nullptr;
+  float* sp = want_stats ? kp.stats + ((size_t)((pn0 + wn * 64) >> 6) * p_cout + cm0 + col0) * 2 : nullptr;
+  char* sw = smem + prow0 * ROWP + col0 * 2;
+  const float osc = kp.out_scale;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    V4 nv[NT];
+    if (bnc) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) nv[nt] = *reinterpret_cast<const V4*>(np[nt] + mt * 16);
+    }
+    float ss4[4] = {0.f, 0.f, 0.f, 0.f}, sq4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float v[4];
+      v[0] = acc[mt][nt][0] + bv[mt].x; v[1] = acc[mt][nt][1] + bv[mt].y;
+      v[2] = acc[mt][nt][2] + bv[mt].z; v[3] = acc[mt][nt][3] + bv[mt].w;
+      if (bnc) {
+        float f[4];
+        Vec4<T>::unpack(nv[nt], f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += f[r];
+      }
+      if (res) {
+        float f[4];
+        Vec4<T>::unpack(rv[mt][nt], f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += f[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= osc;
+      const V4 pk = Vec4<T>::pack(v);
+      *reinterpret_cast<V4*>(sw + nt * 16 * ROWP + mt * 32) = pk;
+      if (want_stats) {                                // moments of the values as stored (rounded to T)
+        float f[4];
+        Vec4<T>::unpack(pk, f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ss4[r] += f[r]; sq4[r] += f[r] * f[r]; }
+      }
+    }
+    if (want_stats) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { ss4[r] += __shfl_xor(ss4[r], o, 64); sq4[r] += __shfl_xor(sq4[r], o, 64); }
+      }
+      if (lrow == 0) {
+        float4* d = reinterpret_cast<float4*>(sp + mt * 32);
+        d[0] = make_float4(ss4[0], sq4[0], ss4[1], sq4[1]);
+        d[1] = make_float4(ss4[2], sq4[2], ss4[3], sq4[3]);
+      }
+    }
+  }
+  __syncthreads();
+  // copy-out: 16 bytes per lane, whole rows; (row, chunk) advance incrementally (256 threads = 256 / CPR rows + a remainder)
+  constexpr int CPR = BM / 8, DR = 256 / CPR, DC = 256 - DR * CPR, ITERS = BN * CPR / 256;
+  static_assert(BN * CPR % 256 == 0, "copy-out trips");
+  int row = (int)threadIdx.x / CPR, c = (int)threadIdx.x - row * CPR;
+  char* outb = kp.out + ((size_t)pn0 * p_cout + cm0) * 2;
+  const size_t rstride = (size_t)p_cout * 2;
+  typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int u = 0; u < ITERS; ++u) {
+    const u32x4_nt v_ = *reinterpret_cast<const u32x4_nt*>(smem + row * ROWP + c * 16);
+    __builtin_nontemporal_store(v_, reinterpret_cast<u32x4_nt*>(outb + row * rstride + c * 16));
+    row += DR; c += DC;
+    if (c >= CPR) { c -= CPR; ++row; }
+  }
+}
+
 // ---- epilogue of one (cout tile, pixel tile[, K split]): lane holds couts co..co+3 of pixel pp for each (mt, nt)
 template <typename T, int MT, int NT, int BM, int BN>
 __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT][NT], int cm0, int pn0, int split, int wm, int wn,
@@ -158,6 +266,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
       }
     }
     return;
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (pn0 + BN <= p_P) {                             // block-uniform
+      conv_epilogue_fast<T, MT, NT, BM, BN>(kp, acc, cm0, pn0, wm, wn, lrow, lq, smem);
+      return;
+    }
   }
   // Epilogue, one 16-cout slice (mt) at a time; interleaved load->store pairs would serialise a memory round trip per
   // (mt, nt) because the compiler must assume `out` aliases the inputs, so the reads are hoisted by hand.
@@ -263,7 +377,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
 #pragma unroll 4
     for (int t = threadIdx.x; t < rows * CPR; t += 256) {
       const int row = t / CPR, c = t - row * CPR;
-      *reinterpret_cast<uint4*>(outb + (size_t)row * p_cout * 2 + c * 16) = *reinterpret_cast<const uint4*>(smem + row * ROWP + c * 16);
+      typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
+      const u32x4_nt v_ = *reinterpret_cast<const u32x4_nt*>(smem + row * ROWP + c * 16);
+      __builtin_nontemporal_store(v_, reinterpret_cast<u32x4_nt*>(outb + (size_t)row * p_cout * 2 + c * 16));
     }
   }
 }
@@ -496,7 +612,6 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes) {
   q.splits = splits;
   q.partial = ws;
   if (splits > 1 || NT != 4) q.stats = nullptr;              // the split-K reduce pass does not produce statistics
-  g_stats_written = q.stats != nullptr;
   const size_t lds = (size_t)2 * (BM + BN) * 128;
   static bool attr_done = false;
   if (!attr_done) {
