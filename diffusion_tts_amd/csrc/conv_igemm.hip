@@ -612,6 +612,7 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes) {
   q.splits = splits;
   q.partial = ws;
   if (splits > 1 || NT != 4) q.stats = nullptr;              // the split-K reduce pass does not produce statistics
+  g_stats_written = q.stats != nullptr;
   const size_t lds = (size_t)2 * (BM + BN) * 128;
   static bool attr_done = false;
   if (!attr_done) {
