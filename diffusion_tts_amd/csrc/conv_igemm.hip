@@ -143,7 +143,7 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((ch
 // the generic epilogue below executes ~1.5k instructions per wave (a predicated branch per access, a 64-bit address per
 // vector), which in-kernel stamps put at 9k cycles per block -- as long as 4 K steps -- before the first byte is stored.
 // Arithmetic and its order are the generic path's: ((acc + bias) + bias_nc + residual) * out_scale, rounded once.
-template <typename T, int MT, int NT, int BM, int BN>
+template <typename T, int MT, int NT, int BM, int BN, bool RES, bool BNC, bool STATS>
 __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&acc)[MT][NT], int cm0, int pn0, int wm, int wn, int lrow,
                                                    int lq, char* smem) {
   using V4 = typename Vec4<T>::type;
@@ -162,7 +162,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
     for (int mt = 0; mt < MT; ++mt) bv[mt] = *reinterpret_cast<const float4*>(bp + mt * 16);
   }
   V4 rv[MT][NT];
-  if (res) {
+  if constexpr (RES) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const T* rp = res + (size_t)(pn0 + prow0 + nt * 16) * p_cout + cm0 + col0;
@@ -171,19 +171,19 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
     }
   }
   const T* np[NT];
-  if (bnc) {
+  if constexpr (BNC) {
     const int hw = kp.hout * kp.wout;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) np[nt] = bnc + (size_t)((pn0 + prow0 + nt * 16) / hw) * kp.ld_bias_nc + cm0 + col0;
   }
-  const bool want_stats = NT == 4 && kp.stats != nullptr;
+  constexpr bool want_stats = STATS && NT == 4;
   float* sp = want_stats ? kp.stats + ((size_t)((pn0 + wn * 64) >> 6) * p_cout + cm0 + col0) * 2 : nullptr;
   char* sw = smem + prow0 * ROWP + col0 * 2;
   const float osc = kp.out_scale;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     V4 nv[NT];
-    if (bnc) {
+    if constexpr (BNC) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) nv[nt] = *reinterpret_cast<const V4*>(np[nt] + mt * 16);
     }
@@ -193,13 +193,13 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
       float v[4];
       v[0] = acc[mt][nt][0] + bv[mt].x; v[1] = acc[mt][nt][1] + bv[mt].y;
       v[2] = acc[mt][nt][2] + bv[mt].z; v[3] = acc[mt][nt][3] + bv[mt].w;
-      if (bnc) {
+      if constexpr (BNC) {
         float f[4];
         Vec4<T>::unpack(nv[nt], f);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += f[r];
       }
-      if (res) {
+      if constexpr (RES) {
         float f[4];
         Vec4<T>::unpack(rv[mt][nt], f);
 #pragma unroll
@@ -209,14 +209,14 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
       for (int r = 0; r < 4; ++r) v[r] *= osc;
       const V4 pk = Vec4<T>::pack(v);
       *reinterpret_cast<V4*>(sw + nt * 16 * ROWP + mt * 32) = pk;
-      if (want_stats) {                                // moments of the values as stored (rounded to T)
+      if constexpr (want_stats) {                      // moments of the values as stored (rounded to T)
         float f[4];
         Vec4<T>::unpack(pk, f);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ss4[r] += f[r]; sq4[r] += f[r] * f[r]; }
       }
     }
-    if (want_stats) {
+    if constexpr (want_stats) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -269,7 +269,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
   }
   if constexpr (sizeof(T) == 2) {
     if (pn0 + BN <= p_P) {                             // block-uniform
-      conv_epilogue_fast<T, MT, NT, BM, BN>(kp, acc, cm0, pn0, wm, wn, lrow, lq, smem);
+      const bool r_ = kp.residual != nullptr, b_ = kp.bias_nc != nullptr, s_ = NT == 4 && kp.stats != nullptr;
+#define DTS_EPI(R_, B_, S_) conv_epilogue_fast<T, MT, NT, BM, BN, R_, B_, S_>(kp, acc, cm0, pn0, wm, wn, lrow, lq, smem)
+      if (r_) { if (b_) { if (s_) DTS_EPI(true, true, true); else DTS_EPI(true, true, false); }
+                else    { if (s_) DTS_EPI(true, false, true); else DTS_EPI(true, false, false); } }
+      else    { if (b_) { if (s_) DTS_EPI(false, true, true); else DTS_EPI(false, true, false); }
+                else    { if (s_) DTS_EPI(false, false, true); else DTS_EPI(false, false, false); } }
+#undef DTS_EPI
       return;
     }
   }

@@ -16,6 +16,10 @@ rep("  const int lrow = lane & 15, lq = lane >> 4;\n  int buf = 0;",
     "  const unsigned long long tsB = __builtin_amdgcn_s_memtime();\n  const int lrow = lane & 15, lq = lane >> 4;\n  int buf = 0;")
 rep("                                                   int lq, char* smem) {",
     "                                                   int lq, char* smem, unsigned long long* estamp = nullptr) {")
+rep("  V4 rv[MT][NT];\n  if (res) {\n#pragma unroll\n    for (int nt = 0; nt < NT; ++nt) {\n      const T* rp = res",
+    "  if (estamp) estamp[2] = __builtin_amdgcn_s_memtime();\n  V4 rv[MT][NT];\n  if (res) {\n#pragma unroll\n    for (int nt = 0; nt < NT; ++nt) {\n      const T* rp = res")
+rep("  const bool want_stats = NT == 4 && kp.stats != nullptr;\n  float* sp = want_stats ? kp.stats + ((size_t)((pn0 + wn * 64) >> 6) * p_cout + cm0 + col0) * 2 : nullptr;",
+    "  asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n  if (estamp) estamp[3] = __builtin_amdgcn_s_memtime();\n  const bool want_stats = NT == 4 && kp.stats != nullptr;\n  float* sp = want_stats ? kp.stats + ((size_t)((pn0 + wn * 64) >> 6) * p_cout + cm0 + col0) * 2 : nullptr;")
 rep("  __syncthreads();\n  // copy-out: 16 bytes per lane, whole rows;",
     "  if (estamp) estamp[0] = __builtin_amdgcn_s_memtime();\n  __syncthreads();\n  if (estamp) estamp[1] = __builtin_amdgcn_s_memtime();\n  // copy-out: 16 bytes per lane, whole rows;")
 rep("                                              int lrow, int lq, char* smem) {",
@@ -23,14 +27,14 @@ rep("                                              int lrow, int lq, char* smem)
 rep("      conv_epilogue_fast<T, MT, NT, BM, BN>(kp, acc, cm0, pn0, wm, wn, lrow, lq, smem);",
     "      conv_epilogue_fast<T, MT, NT, BM, BN>(kp, acc, cm0, pn0, wm, wn, lrow, lq, smem, estamp);")
 rep("  conv_epilogue<T, MT, NT, BM, BN>(kp, acc, cm0, pn0, (int)blockIdx.y, wm, wn, lrow, lq, smem);\n}", '''  const unsigned long long tsC = __builtin_amdgcn_s_memtime();
-  unsigned long long est[2] = {0, 0};
+  unsigned long long est[4] = {0, 0, 0, 0};
   conv_epilogue<T, MT, NT, BM, BN>(kp, acc, cm0, pn0, (int)blockIdx.y, wm, wn, lrow, lq, smem, est);
   const unsigned long long tsD = __builtin_amdgcn_s_memtime();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const unsigned long long tsE = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
   if (kp.splits == 1 && kp.partial != nullptr && threadIdx.x == 0) {
-    unsigned long long* d = reinterpret_cast<unsigned long long*>(kp.partial) + (size_t)blockIdx.x * 10;
-    d[0] = tsA; d[1] = tsB; d[2] = tsC; d[3] = est[0]; d[4] = est[1]; d[5] = tsD; d[6] = tsE; d[7] = rt0; d[8] = rt1;
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(kp.partial) + (size_t)blockIdx.x * 12;
+    d[0] = tsA; d[1] = tsB; d[2] = tsC; d[3] = est[0]; d[4] = est[1]; d[5] = tsD; d[6] = tsE; d[7] = rt0; d[8] = rt1; d[9] = est[2]; d[10] = est[3];
   }
 }''')
 tmp = '/tmp/conv_diag.hip'
