@@ -47,6 +47,7 @@ struct ConvP {
   float* partial;  // [splits][P][cout] f32 when splits > 1
   float* stats;    // optional [ceil(P/64)][cout][2]: per 64-pixel strip (sum, sumsq) of the stored outputs (GroupNorm input)
   float out_scale;
+  int w_shift, hw_shift;   // log2(wout), log2(hout*wout) when both are powers of two, else -1 (pixel coordinates by division)
 };
 
 template <typename T> struct Mma;
@@ -145,7 +146,7 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((ch
 // Arithmetic and its order are the generic path's: ((acc + bias) + bias_nc + residual) * out_scale, rounded once.
 template <typename T, int MT, int NT, int BM, int BN, bool RES, bool BNC, bool STATS>
 __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&acc)[MT][NT], int cm0, int pn0, int wm, int wn, int lrow,
-                                                   int lq, char* smem) {
+                                                   int lq, char* smem, bool bias_in_acc) {
   using V4 = typename Vec4<T>::type;
   constexpr int ROWP = BM * 2 + 16;
   const int p_cout = kp.cout;
@@ -156,7 +157,8 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
   float4 bv[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) bv[mt] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (kp.bias) {
+  const bool add_bias = kp.bias != nullptr && !bias_in_acc;
+  if (add_bias) {
     const float* bp = kp.bias + cm0 + col0;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) bv[mt] = *reinterpret_cast<const float4*>(bp + mt * 16);
@@ -174,7 +176,10 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
   if constexpr (BNC) {
     const int hw = kp.hout * kp.wout;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) np[nt] = bnc + (size_t)((pn0 + prow0 + nt * 16) / hw) * kp.ld_bias_nc + cm0 + col0;
+    for (int nt = 0; nt < NT; ++nt) {
+      const int pp = pn0 + prow0 + nt * 16;
+      np[nt] = bnc + (size_t)(kp.hw_shift >= 0 ? pp >> kp.hw_shift : pp / hw) * kp.ld_bias_nc + cm0 + col0;
+    }
   }
   constexpr bool want_stats = STATS && NT == 4;
   float* sp = want_stats ? kp.stats + ((size_t)((pn0 + wn * 64) >> 6) * p_cout + cm0 + col0) * 2 : nullptr;
@@ -191,8 +196,8 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       float v[4];
-      v[0] = acc[mt][nt][0] + bv[mt].x; v[1] = acc[mt][nt][1] + bv[mt].y;
-      v[2] = acc[mt][nt][2] + bv[mt].z; v[3] = acc[mt][nt][3] + bv[mt].w;
+      v[0] = acc[mt][nt][0]; v[1] = acc[mt][nt][1]; v[2] = acc[mt][nt][2]; v[3] = acc[mt][nt][3];
+      if (add_bias) { v[0] += bv[mt].x; v[1] += bv[mt].y; v[2] += bv[mt].z; v[3] += bv[mt].w; }
       if constexpr (BNC) {
         float f[4];
         Vec4<T>::unpack(nv[nt], f);
@@ -249,7 +254,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
 // ---- epilogue of one (cout tile, pixel tile[, K split]): lane holds couts co..co+3 of pixel pp for each (mt, nt)
 template <typename T, int MT, int NT, int BM, int BN>
 __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT][NT], int cm0, int pn0, int split, int wm, int wn,
-                                              int lrow, int lq, char* smem) {
+                                              int lrow, int lq, char* smem, bool bias_in_acc) {
   const int p_P = kp.P, p_cout = kp.cout, p_hout = kp.hout, p_wout = kp.wout;
   // ---- epilogue: lane holds couts co..co+3 of pixel pp for each (mt, nt): one 4-element vector load/store
   if (kp.splits > 1) {
@@ -270,7 +275,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
   if constexpr (sizeof(T) == 2) {
     if (pn0 + BN <= p_P) {                             // block-uniform
       const bool r_ = kp.residual != nullptr, b_ = kp.bias_nc != nullptr, s_ = NT == 4 && kp.stats != nullptr;
-#define DTS_EPI(R_, B_, S_) conv_epilogue_fast<T, MT, NT, BM, BN, R_, B_, S_>(kp, acc, cm0, pn0, wm, wn, lrow, lq, smem)
+#define DTS_EPI(R_, B_, S_) conv_epilogue_fast<T, MT, NT, BM, BN, R_, B_, S_>(kp, acc, cm0, pn0, wm, wn, lrow, lq, smem, bias_in_acc)
       if (r_) { if (b_) { if (s_) DTS_EPI(true, true, true); else DTS_EPI(true, true, false); }
                 else    { if (s_) DTS_EPI(true, false, true); else DTS_EPI(true, false, false); } }
       else    { if (b_) { if (s_) DTS_EPI(false, true, true); else DTS_EPI(false, true, false); }
@@ -299,7 +304,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
   float4 bv[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
-    bv[mt] = kp.bias ? *reinterpret_cast<const float4*>(kp.bias + cm0 + wm * 16 * MT + mt * 16 + lq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    bv[mt] = (kp.bias && !bias_in_acc) ? *reinterpret_cast<const float4*>(kp.bias + cm0 + wm * 16 * MT + mt * 16 + lq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   if (res) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -434,9 +439,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
   for (int j = 0; j < RB; ++j) {
     const int pp = pn0 + r0 + SLAB * j;
     if (pp < p_P) {
-      const int hw = p_hout * p_wout;
-      const int n = pp / hw, rem = pp - n * hw;
-      const int ho = rem / p_wout, wo = rem - ho * p_wout;
+      int n, ho, wo;
+      if (kp.hw_shift >= 0) {                            // block-uniform: every U-Net level here is a power of two
+        n = pp >> kp.hw_shift;
+        const int rem = pp & ((1 << kp.hw_shift) - 1);
+        ho = rem >> kp.w_shift; wo = rem & ((1 << kp.w_shift) - 1);
+      } else {
+        const int hw = p_hout * p_wout;
+        n = pp / hw;
+        const int rem = pp - n * hw;
+        ho = rem / p_wout; wo = rem - ho * p_wout;
+      }
       pix_n[j] = n * p_hin * p_win;
       pix_hw[j] = (ho << 16) | wo;
     } else {
@@ -490,11 +503,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
     else { _Pragma("unroll") for (int j = 0; j < RB; ++j) brow[j] += BKE * ES; }                              \
   }
 
+  // 16-bit modes start the accumulators at the bias (its load hides behind the first tile fetch) instead of adding it in the
+  // epilogue, where the load latency (~1.5k cycles by the in-kernel stamps) sits on every block's critical path; f32 (parity)
+  // adds it last like the reference, and split-K adds it once in the reduce pass.
+  const bool bias_in_acc = sizeof(T) == 2 && kp.splits == 1 && kp.bias != nullptr;
   f32x4_t acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int i = 0; i < MT; ++i) {
+    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias_in_acc) b0 = *reinterpret_cast<const float4*>(kp.bias + cm0 + wm * 16 * MT + i * 16 + (lane >> 4) * 4);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{b0.x, b0.y, b0.z, b0.w};
+  }
 
   // issue-side K state (tap, cin offset) runs STAGES-1 tiles ahead of the compute side
   int tap = ks_begin / steps_per_tap, ci0 = (ks_begin - tap * steps_per_tap) * BKE;
@@ -553,7 +573,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
     buf ^= 1;
   }
 
-  conv_epilogue<T, MT, NT, BM, BN>(kp, acc, cm0, pn0, (int)blockIdx.y, wm, wn, lrow, lq, smem);
+  conv_epilogue<T, MT, NT, BM, BN>(kp, acc, cm0, pn0, (int)blockIdx.y, wm, wn, lrow, lq, smem, bias_in_acc);
 }
 #undef SET_ROWS
 #undef ISSUE_TILE
@@ -687,6 +707,11 @@ extern "C" int dts_conv2d(const dts_conv_args* a, dts_stream s) {
   DTS_CHECK_ARG(P < (1ll << 30), "dts_conv2d: too many pixels");
   p.P = (int)P; p.out_scale = a->out_scale; p.n_ct = p.n_pt = 0;
   p.splits = 1; p.ks_per_split = 0; p.partial = nullptr;
+  p.w_shift = p.hw_shift = -1;
+  {
+    const int hw = p.hout * p.wout;
+    if ((p.wout & (p.wout - 1)) == 0 && (hw & (hw - 1)) == 0) { p.w_shift = __builtin_ctz(p.wout); p.hw_shift = __builtin_ctz(hw); }
+  }
   p.stats = a->stats_out;
   DTS_CHECK_ARG(a->stats_out == nullptr || ((p.hout * p.wout) % 64 == 0 && (uintptr_t)a->stats_out % 16 == 0),
                 "dts_conv2d: strip statistics need hout*wout to be a multiple of 64 and a 16-byte aligned buffer");
