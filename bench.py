@@ -269,7 +269,8 @@ def main():
         traffic, tsrc = None, None
         try:        # HBM bytes per launch of the dominant kernel from the committed PMC passes (cannot be collected in-process)
             with open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic_pmc.json')) as f:
-                k = json.load(f)['kernels']['conv_igemm_kernel<bf16_t, 6, 4, 2, 2, 2>']
+                ks = json.load(f)['kernels']
+                k = next(v for name, v in ks.items() if name.startswith('conv_igemm_kernel<bf16_t, 6, 4, 2, 2, true>'))   # dominant variant
             if a.dtype == 'bf16' and a.candidates == 64:
                 traffic, tsrc = round(k['hbm_bytes_per_launch']), 'profiles/r01_hbm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)'
         except Exception:
