@@ -148,12 +148,31 @@ template <typename T, int MT, int NT, int BM, int BN, bool RES, bool BNC, bool S
 __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&acc)[MT][NT], int cm0, int pn0, int wm, int wn, int lrow,
                                                    int lq, char* smem, bool bias_in_acc) {
   using V4 = typename Vec4<T>::type;
-  constexpr int ROWP = BM * 2 + 16;
+  // Staged tile in the idle LDS ring: pixel-major rows of BM*2 bytes, dense (LDS-DMA writes 1 KiB contiguous per
+  // wave-instruction, so no padding is possible); the 16-byte chunk c of row r sits at chunk slot c ^ (r & 7), which keeps
+  // the accumulator-layout 8-byte accesses (16 rows per lane group) at 2-way bank conflicts instead of 8-way.
+  constexpr int ROWB = BM * 2, CPR = BM / 8, DR = 256 / CPR, DC = 256 - DR * CPR, ITERS = BN * CPR / 256;
+  static_assert(BN * CPR % 256 == 0 && CPR % 8 == 0, "staged tile trips / swizzle groups");
   const int p_cout = kp.cout;
-  const int prow0 = wn * 16 * NT + lrow;                 // tile-local pixel of nt = 0
+  const int prow0 = wn * 16 * NT + lrow;                 // tile-local pixel of nt = 0; (row & 7) == (lrow & 7) for every nt
   const int col0 = wm * 16 * MT + lq * 4;                // tile-local cout of mt = 0
-  const T* __restrict__ res = reinterpret_cast<const T*>(kp.residual);
   const T* __restrict__ bnc = reinterpret_cast<const T*>(kp.bias_nc);
+  const size_t rstride = (size_t)p_cout * 2;
+  const int tid = threadIdx.x;
+  if constexpr (RES) {
+    // residual tile -> LDS by LDS-DMA, whole rows, 16 bytes per lane (the accumulator-layout loads it replaces were 24
+    // scattered 8-byte reads per lane: ~8k cycles per block by the in-kernel stamps)
+    const char* resb = kp.residual + ((size_t)pn0 * p_cout + cm0) * 2;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t wave_dst = __builtin_amdgcn_readfirstlane(lds0 + (tid >> 6) * 1024);
+    int row = tid / CPR, c = tid - row * CPR;
+#pragma unroll
+    for (int u = 0; u < ITERS; ++u) {
+      glds16(resb + row * rstride + ((c ^ (row & 7)) << 4), wave_dst + u * 4096);
+      row += DR; c += DC;
+      if (c >= CPR) { c -= CPR; ++row; }
+    }
+  }
   float4 bv[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) bv[mt] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -162,15 +181,6 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
     const float* bp = kp.bias + cm0 + col0;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) bv[mt] = *reinterpret_cast<const float4*>(bp + mt * 16);
-  }
-  V4 rv[MT][NT];
-  if constexpr (RES) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const T* rp = res + (size_t)(pn0 + prow0 + nt * 16) * p_cout + cm0 + col0;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) rv[mt][nt] = *reinterpret_cast<const V4*>(rp + mt * 16);
-    }
   }
   const T* np[NT];
   if constexpr (BNC) {
@@ -183,14 +193,26 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
   }
   constexpr bool want_stats = STATS && NT == 4;
   float* sp = want_stats ? kp.stats + ((size_t)((pn0 + wn * 64) >> 6) * p_cout + cm0 + col0) * 2 : nullptr;
-  char* sw = smem + prow0 * ROWP + col0 * 2;
+  // this lane's slot of (mt, nt): row prow0 + 16 nt, chunk (col0 / 8 + 2 mt) ^ (lrow & 7), half lq & 1
+  char* sw = smem + prow0 * ROWB + (lq & 1) * 8;
+  int coff[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) coff[mt] = (((wm * 2 * MT + 2 * mt + (lq >> 1)) ^ (lrow & 7)) << 4);
   const float osc = kp.out_scale;
+  if constexpr (RES) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    V4 nv[NT];
+    V4 nv[NT], rv[NT];
     if constexpr (BNC) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) nv[nt] = *reinterpret_cast<const V4*>(np[nt] + mt * 16);
+    }
+    if constexpr (RES) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) rv[nt] = *reinterpret_cast<const V4*>(sw + nt * 16 * ROWB + coff[mt]);
     }
     float ss4[4] = {0.f, 0.f, 0.f, 0.f}, sq4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -206,14 +228,14 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
       }
       if constexpr (RES) {
         float f[4];
-        Vec4<T>::unpack(rv[mt][nt], f);
+        Vec4<T>::unpack(rv[nt], f);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += f[r];
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] *= osc;
       const V4 pk = Vec4<T>::pack(v);
-      *reinterpret_cast<V4*>(sw + nt * 16 * ROWP + mt * 32) = pk;
+      *reinterpret_cast<V4*>(sw + nt * 16 * ROWB + coff[mt]) = pk;       // the slot this lane read its residual from
       if constexpr (want_stats) {                      // moments of the values as stored (rounded to T)
         float f[4];
         Vec4<T>::unpack(pk, f);
@@ -235,17 +257,14 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
     }
   }
   __syncthreads();
-  // copy-out: 16 bytes per lane, whole rows; (row, chunk) advance incrementally (256 threads = 256 / CPR rows + a remainder)
-  constexpr int CPR = BM / 8, DR = 256 / CPR, DC = 256 - DR * CPR, ITERS = BN * CPR / 256;
-  static_assert(BN * CPR % 256 == 0, "copy-out trips");
-  int row = (int)threadIdx.x / CPR, c = (int)threadIdx.x - row * CPR;
+  // copy-out: 16 bytes per lane, whole rows; (row, chunk slot) advance incrementally (256 threads = DR rows + DC chunks)
+  int row = tid / CPR, c = tid - row * CPR;
   char* outb = kp.out + ((size_t)pn0 * p_cout + cm0) * 2;
-  const size_t rstride = (size_t)p_cout * 2;
   typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int u = 0; u < ITERS; ++u) {
-    const u32x4_nt v_ = *reinterpret_cast<const u32x4_nt*>(smem + row * ROWP + c * 16);
-    __builtin_nontemporal_store(v_, reinterpret_cast<u32x4_nt*>(outb + row * rstride + c * 16));
+    const u32x4_nt v_ = *reinterpret_cast<const u32x4_nt*>(smem + row * ROWB + c * 16);
+    __builtin_nontemporal_store(v_, reinterpret_cast<u32x4_nt*>(outb + row * rstride + ((c ^ (row & 7)) << 4)));
     row += DR; c += DC;
     if (c >= CPR) { c -= CPR; ++row; }
   }

@@ -45,4 +45,6 @@ def run(name, r, cin, cout, k, n=64, bias=True, residual=False):
 
 if __name__ == '__main__':
     run('L0 3x3 192->192', 64, 192, 192, 3)
+    run('L0 3x3 192->192 +residual', 64, 192, 192, 3, residual=True)
+    run('L1 3x3 384->384 +residual', 32, 384, 384, 3, residual=True)
     run('L1 1x1 384->1152', 32, 384, 1152, 1)

@@ -14,21 +14,21 @@ rep("  const int nblk = p_n_ct * p_n_pt;\n  int bid = blockIdx.x;",
     "  const unsigned long long tsA = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();\n  const int nblk = p_n_ct * p_n_pt;\n  int bid = blockIdx.x;")
 rep("  const int lrow = lane & 15, lq = lane >> 4;\n  int buf = 0;",
     "  const unsigned long long tsB = __builtin_amdgcn_s_memtime();\n  const int lrow = lane & 15, lq = lane >> 4;\n  int buf = 0;")
-rep("                                                   int lq, char* smem) {",
-    "                                                   int lq, char* smem, unsigned long long* estamp = nullptr) {")
+rep("                                                   int lq, char* smem, bool bias_in_acc) {",
+    "                                                   int lq, char* smem, bool bias_in_acc, unsigned long long* estamp = nullptr) {")
 rep("  V4 rv[MT][NT];\n  if constexpr (RES) {",
     "  if (estamp) estamp[2] = __builtin_amdgcn_s_memtime();\n  V4 rv[MT][NT];\n  if constexpr (RES) {")
 rep("  constexpr bool want_stats = STATS && NT == 4;\n  float* sp = want_stats ? kp.stats + ((size_t)((pn0 + wn * 64) >> 6) * p_cout + cm0 + col0) * 2 : nullptr;",
     "  asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n  if (estamp) estamp[3] = __builtin_amdgcn_s_memtime();\n  constexpr bool want_stats = STATS && NT == 4;\n  float* sp = want_stats ? kp.stats + ((size_t)((pn0 + wn * 64) >> 6) * p_cout + cm0 + col0) * 2 : nullptr;")
 rep("  __syncthreads();\n  // copy-out: 16 bytes per lane, whole rows;",
     "  if (estamp) estamp[0] = __builtin_amdgcn_s_memtime();\n  __syncthreads();\n  if (estamp) estamp[1] = __builtin_amdgcn_s_memtime();\n  // copy-out: 16 bytes per lane, whole rows;")
-rep("                                              int lrow, int lq, char* smem) {",
-    "                                              int lrow, int lq, char* smem, unsigned long long* estamp = nullptr) {")
-rep("conv_epilogue_fast<T, MT, NT, BM, BN, R_, B_, S_>(kp, acc, cm0, pn0, wm, wn, lrow, lq, smem)",
-    "conv_epilogue_fast<T, MT, NT, BM, BN, R_, B_, S_>(kp, acc, cm0, pn0, wm, wn, lrow, lq, smem, estamp)")
-rep("  conv_epilogue<T, MT, NT, BM, BN>(kp, acc, cm0, pn0, (int)blockIdx.y, wm, wn, lrow, lq, smem);\n}", '''  const unsigned long long tsC = __builtin_amdgcn_s_memtime();
+rep("                                              int lrow, int lq, char* smem, bool bias_in_acc) {",
+    "                                              int lrow, int lq, char* smem, bool bias_in_acc, unsigned long long* estamp = nullptr) {")
+rep("conv_epilogue_fast<T, MT, NT, BM, BN, R_, B_, S_>(kp, acc, cm0, pn0, wm, wn, lrow, lq, smem, bias_in_acc)",
+    "conv_epilogue_fast<T, MT, NT, BM, BN, R_, B_, S_>(kp, acc, cm0, pn0, wm, wn, lrow, lq, smem, bias_in_acc, estamp)")
+rep("  conv_epilogue<T, MT, NT, BM, BN>(kp, acc, cm0, pn0, (int)blockIdx.y, wm, wn, lrow, lq, smem, bias_in_acc);\n}", '''  const unsigned long long tsC = __builtin_amdgcn_s_memtime();
   unsigned long long est[4] = {0, 0, 0, 0};
-  conv_epilogue<T, MT, NT, BM, BN>(kp, acc, cm0, pn0, (int)blockIdx.y, wm, wn, lrow, lq, smem, est);
+  conv_epilogue<T, MT, NT, BM, BN>(kp, acc, cm0, pn0, (int)blockIdx.y, wm, wn, lrow, lq, smem, bias_in_acc, est);
   const unsigned long long tsD = __builtin_amdgcn_s_memtime();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const unsigned long long tsE = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
