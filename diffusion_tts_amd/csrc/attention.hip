@@ -159,11 +159,9 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
       for (int dt = 0; dt < DT; ++dt) {
         const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(va + dt * 32));
         const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vb + dt * 32));
-        uint4 av;
-        av.x = (uint16_t)lo[0] | ((uint32_t)(uint16_t)lo[1] << 16);
-        av.y = (uint16_t)lo[2] | ((uint32_t)(uint16_t)lo[3] << 16);
-        av.z = (uint16_t)hi[0] | ((uint32_t)(uint16_t)hi[1] << 16);
-        av.w = (uint16_t)hi[2] | ((uint32_t)(uint16_t)hi[3] << 16);
+        // the two transposed 8-byte reads ARE the operand's four dwords (element-wise repacking compiled to 16 shift/or ops)
+        const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi);
+        const uint4 av = make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
         o[dt] = AttMma<T>::run(av, pb, o[dt]);
       }
     }
