@@ -88,6 +88,7 @@ def parse():
     ap.add_argument('--scorer', default='imagenet', choices=['imagenet', 'brightness'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--conv-table', action='store_true', help='log the per-shape conv launch table of the instrumented steps')
     ap.add_argument('--cpu-sample', type=int, default=32, help='candidates in the CPU-baseline sample')
     return ap.parse_args()
 
@@ -252,7 +253,10 @@ def main():
             out = orig(x1, w, bias, **kw)
             e1 = hev.record()
             n_, ho, wo, co = out.shape
-            rec.append((2.0 * n_ * ho * wo * co * w.shape[1] * w.shape[2] * w.shape[3], e0, e1))
+            rec.append((2.0 * n_ * ho * wo * co * w.shape[1] * w.shape[2] * w.shape[3], e0, e1,
+                        (tuple(x1.shape), tuple(w.shape), 'x2' if kw.get('x2') is not None else '', 'up' if kw.get('up') else '',
+                         'res' if kw.get('residual') is not None else '', 'bnc' if kw.get('bias_nc') is not None else '',
+                         'stats' if kw.get('gn_stats') else '')))
             return out
         ops.conv2d = timed_conv
         try:
@@ -263,6 +267,13 @@ def main():
             ops.conv2d = orig
         fl = sum(r[0] for r in rec)
         ms = sum(hev.elapsed_ms(r[1], r[2]) for r in rec)
+        if a.conv_table:                      # per-shape view of the conv launches inside the network (stderr)
+            agg = {}
+            for r in rec:
+                t = agg.setdefault(r[3], [0, 0.0, 0.0])
+                t[0] += 1; t[1] += r[0]; t[2] += hev.elapsed_ms(r[1], r[2])
+            for k_, (c_, f_, m_) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
+                log(f'conv {str(k_):100s} x{c_:4d}  {m_ / min(2, a.steps):7.3f} ms/step  {f_ / m_ / 1e9:7.1f} TFLOP/s')
         hev.close()
         ach = fl / (ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[a.dtype]

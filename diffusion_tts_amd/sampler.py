@@ -47,7 +47,8 @@ class SamplingParams:                # edm/main.py:35-43
 
 def load_network(spec, device='cuda', dtype=torch.bfloat16):
     """`network_pkl` argument of generate_image_grid.  The reference unpickles an NVIDIA EDM checkpoint from a URL
-    (edm/main.py:69-70); checkpoints cannot be fetched here, so accepted forms are: a ready network object; a
+    (edm/main.py:69-70); URLs cannot be fetched here, so accepted forms are: a ready network object; the local path of
+    an EDM network pickle (`*.pkl`, read by checkpoint.load_edm_pickle without executing its embedded source); a
     torch-saved dict {'cfg': EDMConfig kwargs, 'state_dict': {...reference keys...}}; or 'random:<preset>[:seed]'
     with preset in {adm_imagenet64, ddpmpp_cifar10} (random init + the documented weight rule)."""
     from . import init as dinit
@@ -64,8 +65,14 @@ def load_network(spec, device='cuda', dtype=torch.bfloat16):
     if isinstance(spec, str) and spec.endswith(('.pt', '.pth')):
         blob = torch.load(spec, map_location='cpu')
         return EDMPrecond(EDMConfig(**blob['cfg']), blob['state_dict'], device=device, dtype=dtype)
-    raise ValueError(f'cannot load network from {spec!r}: EDM pickles embed the reference source and need its '
-                     f'persistence module; pass a network object, a .pt state-dict bundle or "random:<preset>"')
+    if isinstance(spec, str) and spec.endswith('.pkl'):
+        # an NVIDIA EDM network pickle, e.g. a downloaded edm-imagenet-64x64-cond-adm.pkl (the reference's `network_pkl`,
+        # main.py:157-158): weights and constructor arguments are read without executing the source embedded in the file
+        from .checkpoint import load_edm_pickle
+        cfg, sd = load_edm_pickle(spec)
+        return EDMPrecond(cfg, sd, device=device, dtype=dtype)
+    raise ValueError(f'cannot load network from {spec!r}: pass a network object, an EDM network .pkl (local path), a .pt '
+                     f'state-dict bundle or "random:<preset>[:seed]" (URLs cannot be fetched here)')
 
 
 class _Loop:

@@ -48,3 +48,64 @@ def oracle_cls_cfg(cfg: ClassifierConfig):
 
 def T(a):
     return torch.from_numpy(np.asarray(a))
+
+
+def synthetic_edm_pickle(cfg, sd, precond='EDMPrecond'):
+    """Bytes of a pickle with the layout of an NVIDIA EDM network pickle (edm/torch_utils/persistence.py:123-131): nested
+    `torch_utils.persistence._reconstruct_persistent_obj(meta)` calls whose `state` is a torch.nn.Module `__dict__`.  The
+    `module_src` field, which in a real file carries the reference's networks.py, holds a placeholder: this fixture contains
+    no reference text.  tests/golden/check_pkl_loader.py checks the same reader against reference-written pickles."""
+    import collections
+    import pickle
+    import sys
+    import types
+
+    def _reconstruct_persistent_obj(meta):          # never called: only its qualified name is pickled
+        raise RuntimeError
+
+    mod = types.ModuleType('torch_utils.persistence')
+    _reconstruct_persistent_obj.__module__ = 'torch_utils.persistence'
+    _reconstruct_persistent_obj.__qualname__ = '_reconstruct_persistent_obj'
+    mod._reconstruct_persistent_obj = _reconstruct_persistent_obj
+    pkg = types.ModuleType('torch_utils')
+    pkg.persistence = mod
+
+    class Obj:
+        def __init__(self, class_name, **attrs):
+            self.class_name = class_name
+            self.state = dict(training=False, _parameters=collections.OrderedDict(), _buffers=collections.OrderedDict(),
+                              _non_persistent_buffers_set=set(), _modules=collections.OrderedDict(), **attrs)
+
+        def __reduce__(self):
+            meta = dict(type='class', version=6, module_src='# (source text omitted in the synthetic fixture)',
+                        class_name=self.class_name, state=self.state)
+            return (_reconstruct_persistent_obj, (meta,))
+
+    adm = cfg.arch == 'adm'
+    init_kwargs = dict(img_resolution=cfg.img_resolution, in_channels=cfg.img_channels, out_channels=cfg.img_channels,
+                       label_dim=cfg.label_dim, model_channels=cfg.model_channels, channel_mult=list(cfg.channel_mult),
+                       num_blocks=cfg.num_blocks, attn_resolutions=list(cfg.attn_resolutions), augment_dim=cfg.augment_dim)
+    if not adm:
+        init_kwargs.update(embedding_type='positional', encoder_type='standard', decoder_type='standard', channel_mult_noise=1,
+                           resample_filter=[1, 1], dropout=0.13)
+    top = Obj(precond, img_resolution=cfg.img_resolution, img_channels=cfg.img_channels, label_dim=cfg.label_dim, use_fp16=False,
+              sigma_min=cfg.sigma_min, sigma_max=cfg.sigma_max, sigma_data=cfg.sigma_data, _init_args=(), _init_kwargs=None)
+    model = Obj('DhariwalUNet' if adm else 'SongUNet', _init_args=(), _init_kwargs=init_kwargs)
+    top.state['_modules']['model'] = model
+    for key, value in sd.items():
+        parts = key.split('.')
+        assert parts[0] == 'model'
+        node = model
+        for name in parts[1:-1]:
+            node = node.state['_modules'].setdefault(name, Obj('Module'))
+        node.state['_parameters'][parts[-1]] = torch.nn.Parameter(value.clone(), requires_grad=False)
+    saved = {k: sys.modules.get(k) for k in ('torch_utils', 'torch_utils.persistence')}
+    sys.modules['torch_utils'], sys.modules['torch_utils.persistence'] = pkg, mod
+    try:
+        return pickle.dumps(dict(ema=top))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v

@@ -231,3 +231,16 @@ def test_precomputed_noise_hooks_and_edge_sizes(pkg, golden, manifest):
     # degenerate sizes
     both('eps_greedy', dict(N=1, K=1, lambda_param=0.15, eps=0.4), None)
     both('rejection', dict(N=1), None)
+
+
+def test_network_pkl_path_loads_like_the_state_dict(pkg, golden, manifest, tmp_path):
+    """generate_image_grid(network_pkl='*.pkl'): an EDM network pickle (layout of edm/torch_utils/persistence.py) gives the
+    same denoiser as its state dict (checkpoint.load_edm_pickle; no embedded source is executed)."""
+    from helpers import synthetic_edm_pickle
+    cfg, sd = tiny_edm(manifest, 'adm_tiny')
+    path = tmp_path / 'network-snapshot.pkl'
+    path.write_bytes(synthetic_edm_pickle(cfg, sd))
+    net_a = pkg['sampler'].load_network(str(path), device=DEV, dtype=torch.float32)
+    net_b = hip_net(pkg, manifest, 'adm_tiny', torch.float32)
+    x, sig, lab = T(golden['fwd_adm_tiny_hi_x']), T(golden['fwd_adm_tiny_hi_sigma']), T(golden['fwd_labels'])
+    assert torch.equal(net_a(x, sig, lab), net_b(x, sig, lab))
