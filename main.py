@@ -9,7 +9,8 @@ Arguments (verbatim from the reference):
     --method    : naive | rejection | beam | mcts | zero_order | eps_greedy (default naive)
     --prompt, --output, --N, --lambda_, --eps, --K, --B, --S, --seed, --device
 Additions (the reference hard-codes a checkpoint URL, main.py:157-158; there is no network here):
-    --network   : 'random:adm_imagenet64[:seed]' (default), 'random:ddpmpp_cifar10[:seed]', or a .pt bundle
+    --network   : 'random:adm_imagenet64[:seed]' (default), 'random:ddpmpp_cifar10[:seed]', the local path of an NVIDIA EDM
+                  network pickle (*.pkl, read without executing its embedded source), or a .pt bundle
     --dtype     : bf16 (default) | f16 | f32 (parity mode)
 Multi-GPU: launch with `python -m torch.distributed.run --nproc-per-node N main.py ...`; the N candidates of every
 search iteration are sharded across the ranks (diffusion_tts_amd/parallel.py).
