@@ -15,9 +15,11 @@ import torch.distributed as dist
 
 
 class CandidateShards:
-    def __init__(self, group=None):
+    def __init__(self, group=None, enabled=True):
+        """enabled=False: a world-of-one view even inside an initialised process group (seed-sharded bulk generation runs
+        whole searches per rank, bulk.py)."""
         self.group = group
-        self.enabled = dist.is_available() and dist.is_initialized()
+        self.enabled = enabled and dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank(group) if self.enabled else 0
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.collectives = 0

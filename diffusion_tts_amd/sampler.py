@@ -382,7 +382,7 @@ def generate_image_grid(
     sampling_params: Optional[Dict[str, Any]] = None,
     precomputed_noise: Optional[Dict[Any, torch.Tensor]] = None,
     *, scale_fn: Callable[[int, int, int], float] = builtin_scale, compute_dtype=torch.bfloat16, verbose=True,
-    reuse_winner: Optional[bool] = None, record_noises: bool = False,
+    reuse_winner: Optional[bool] = None, record_noises: bool = False, shard_candidates: bool = True,
 ):
     """Same positional/keyword surface as edm/main.py:47-55.  Keyword-only extras: `scale_fn` (the hash-derived step
     table, edm/main.py:776), `compute_dtype` (float32 = parity mode), `verbose`, `reuse_winner` (see below), `record_noises`
@@ -396,7 +396,7 @@ def generate_image_grid(
     if verbose:
         print(f'Using sampling method: {sampling_method.name}')
     net = load_network(network_pkl, device=device, dtype=compute_dtype)
-    shards = CandidateShards()
+    shards = CandidateShards(enabled=shard_candidates)     # False: this rank runs the whole search (bulk.py shards seeds instead)
     step_indices = torch.arange(num_steps, dtype=torch.float64)                       # edm/main.py:78-80 (host)
     t_steps = (sigma_max ** (1 / rho) + step_indices / (num_steps - 1) * (sigma_min ** (1 / rho) - sigma_max ** (1 / rho))) ** rho
     t_steps = torch.cat([net.round_sigma(t_steps), torch.zeros_like(t_steps[:1])])
@@ -415,7 +415,7 @@ def generate_image_grid(
     if verbose:
         print(f'Average score: {avg_score}')
     img_cpu = image.cpu()
-    if dest_path is not None and shards.rank == 0:
+    if dest_path is not None and (shards.rank == 0 or not shard_candidates):
         import PIL.Image
         if verbose:
             print(f'Saving image grid to "{dest_path}"...')

@@ -12,6 +12,8 @@ Additions (the reference hard-codes a checkpoint URL, main.py:157-158; there is 
     --network   : 'random:adm_imagenet64[:seed]' (default), 'random:ddpmpp_cifar10[:seed]', the local path of an NVIDIA EDM
                   network pickle (*.pkl, read without executing its embedded source), or a .pt bundle
     --dtype     : bf16 (default) | f16 | f32 (parity mode)
+    --seeds LIST --outdir DIR [--subdirs] [--class N]: bulk mode (flags of the reference's edm/generate.py): one search per
+                  seed, <outdir>/<seed:06d>.png; with torch.distributed.run the SEEDS are split over the ranks (no collective)
 Multi-GPU: launch with `python -m torch.distributed.run --nproc-per-node N main.py ...`; the N candidates of every
 search iteration are sharded across the ranks (diffusion_tts_amd/parallel.py).
 """
@@ -100,6 +102,10 @@ def main(argv=None):
     parser.add_argument('--device', type=str, default='cuda', help='Device')
     parser.add_argument('--network', type=str, default='random:adm_imagenet64', help='EDM network spec (see module docstring)')
     parser.add_argument('--dtype', type=str, default='bf16', choices=['bf16', 'f16', 'f32'], help='activation dtype')
+    parser.add_argument('--seeds', type=str, default=None, help='bulk mode: seeds, e.g. 0-63 or 1,2,5-10 (one image per seed)')
+    parser.add_argument('--outdir', type=str, default='out', help='bulk mode: output directory')
+    parser.add_argument('--subdirs', action='store_true', help='bulk mode: one subdirectory per 1000 seeds')
+    parser.add_argument('--class', dest='class_idx', type=int, default=None, help='bulk mode: class label (default: per-seed random)')
     args = parser.parse_args(argv)
 
     if args.backend == 'sd' and args.scorer == 'imagenet':
@@ -126,6 +132,21 @@ def main(argv=None):
     dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[args.dtype]
     scorer = get_scorer('edm', args.scorer, device)
     net = load_network(args.network, device=device, dtype=dtype)
+    if args.seeds is not None:                                                        # bulk mode: seeds sharded over the ranks
+        from diffusion_tts_amd.bulk import generate_seeds
+        mm = {'naive': SamplingMethod.NAIVE, 'rejection': SamplingMethod.REJECTION_SAMPLING, 'beam': SamplingMethod.BEAM_SEARCH,
+              'mcts': SamplingMethod.MCTS, 'zero_order': SamplingMethod.ZERO_ORDER, 'eps_greedy': SamplingMethod.EPS_GREEDY}
+        sp = {'scorer': scorer}
+        if args.method != 'naive':
+            sp.update(N=args.N, K=args.K, lambda_param=args.lambda_, eps=args.eps, B=args.B, S=args.S)
+        done = generate_seeds(net, args.seeds, args.outdir, sampling_method=mm[args.method], sampling_params=sp,
+                              class_idx=args.class_idx, subdirs=args.subdirs, device=device, compute_dtype=dtype,
+                              num_steps=18, S_churn=40, S_min=0.05, S_max=50, S_noise=1.003)
+        print(f'[EDM] rank {os.environ.get("RANK", "0")}: {len(done)} images -> {args.outdir}')
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return done
     num_images = 1
     r = net.img_resolution
     latents = torch.randn([num_images, net.img_channels, r, r])                       # drawn before seeding, as main.py:161

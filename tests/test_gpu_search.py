@@ -244,3 +244,26 @@ def test_network_pkl_path_loads_like_the_state_dict(pkg, golden, manifest, tmp_p
     net_b = hip_net(pkg, manifest, 'adm_tiny', torch.float32)
     x, sig, lab = T(golden['fwd_adm_tiny_hi_x']), T(golden['fwd_adm_tiny_hi_sigma']), T(golden['fwd_labels'])
     assert torch.equal(net_a(x, sig, lab), net_b(x, sig, lab))
+
+
+def test_bulk_generation_by_seed(pkg, manifest, tmp_path):
+    """bulk.generate_seeds: one search per seed, PNG per seed, and a seed's image is the one generate_image_grid gives for
+    the same latents/labels/seed (so it cannot depend on how the seeds are split over ranks)."""
+    from diffusion_tts_amd import bulk
+    sm, S = pkg['sampler'], pkg['scorers']
+    net = hip_net(pkg, manifest, 'adm_tiny', torch.float32)
+    params = dict(scorer=S.BrightnessScorer(), N=3, K=2, lambda_param=0.15, eps=0.4)
+    kw = dict(num_steps=3, S_churn=40, S_min=0.05, S_max=50, S_noise=1.003, scale_fn=seed0_scale)
+    done = bulk.generate_seeds(net, '5,7-8', str(tmp_path), sampling_method=sm.SamplingMethod.EPS_GREEDY, sampling_params=params,
+                               subdirs=True, device=DEV, compute_dtype=torch.float32, **kw)
+    assert sorted(done) == [5, 7, 8]
+    for seed in done:
+        assert os.path.exists(tmp_path / '000000' / f'{seed:06d}.png')
+    lat, lab = bulk.seed_inputs(7, net)
+    one = sm.generate_image_grid(net, None, lat, lab, seed=7, gridw=1, gridh=1, device=torch.device(DEV),
+                                 sampling_method=sm.SamplingMethod.EPS_GREEDY, sampling_params=params, compute_dtype=torch.float32,
+                                 verbose=False, **kw)
+    assert torch.equal(one['image'], done[7]['image'])
+    import PIL.Image
+    png = np.array(PIL.Image.open(tmp_path / '000000' / '000007.png'))
+    assert np.array_equal(png, done[7]['image'][0].permute(1, 2, 0).numpy())

@@ -69,3 +69,40 @@ def test_single_process_is_a_noop():
     assert (sh.rank, sh.world) == (0, 1) and sh.span(5) == (0, 5)
     x = torch.arange(5.0)
     assert sh.gather_rewards(x, 5, 1) is x and sh.collectives == 0
+
+
+def _bulk_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from diffusion_tts_amd.bulk import rank_batches
+        from diffusion_tts_amd.parallel import CandidateShards
+        mine = [s for b in rank_batches(range(10, 31), 4, dist.get_rank(), dist.get_world_size()) for s in b.tolist()]
+        off = CandidateShards(enabled=False)                              # whole searches per rank: no candidate sharding
+        assert (off.rank, off.world, off.enabled) == (0, 1, False)
+        loc = torch.arange(5, dtype=torch.float32)
+        assert off.gather_rewards(loc, 5, 1) is loc and off.collectives == 0
+        q.put((rank, mine))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_seed_sharding_world2_gloo():
+    """bulk generation: the seeds are split like edm/generate.py:259-261 (tensor_split, rank::world); together the ranks cover
+    every seed exactly once, with no collective on the data path."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bulk_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(got[0] + got[1]) == list(range(10, 31)) and not set(got[0]) & set(got[1])
+    from diffusion_tts_amd.bulk import rank_batches, parse_int_list
+    ref = torch.as_tensor(list(range(10, 31))).tensor_split(((21 - 1) // (4 * 2) + 1) * 2)
+    assert got[0] == [s for b in ref[0::2] for s in b.tolist()] and got[1] == [s for b in ref[1::2] for s in b.tolist()]
+    assert parse_int_list('1,2,5-8') == [1, 2, 5, 6, 7, 8]
+    assert [b.tolist() for b in rank_batches([3, 4, 5], 64, 0, 1)] == [[3, 4, 5]]
