@@ -37,7 +37,9 @@ struct AttP {
 
 // ------------------------------------------------------------------------------------------------
 // 16-bit element types
-template <typename T, int D>
+// QT = query tiles (of 16) per wave: a block covers 64*QT queries.  QT = 2 halves the K/V staging, the barriers and the K / V^T
+// fragment reads per query (each fragment feeds both query tiles); used for long sequences, where the grid stays large.
+template <typename T, int D, int QT>
 __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
   constexpr int ES = 2, ROWB = D * ES + 32;        // LDS row stride in bytes
   constexpr int CH = D / 8;                        // 16-byte chunks per row
@@ -52,23 +54,29 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
   const int C = p.heads * D;
   const size_t rowstride = (size_t)3 * C * ES;
   const char* base = p.qkv + (size_t)n * p.t * rowstride + (size_t)head * D * ES;
-  const int q0 = blockIdx.x * 64 + wid * 16;
-  const int qrow = q0 + lq;
+  const int q0 = blockIdx.x * (64 * QT) + wid * (16 * QT);
 
   // Q fragments: B operand, lane holds Q[q][8*(lg + 4s) .. +8]
-  uint4 qf[KSTEPS];
+  uint4 qf[QT][KSTEPS];
 #pragma unroll
-  for (int s = 0; s < KSTEPS; ++s) {
-    qf[s] = make_uint4(0, 0, 0, 0);
-    if (qrow < p.t) qf[s] = *reinterpret_cast<const uint4*>(base + (size_t)qrow * rowstride + (lg + 4 * s) * 16);
-  }
+  for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      const int qrow = q0 + qt * 16 + lq;
+      qf[qt][s] = make_uint4(0, 0, 0, 0);
+      if (qrow < p.t) qf[qt][s] = *reinterpret_cast<const uint4*>(base + (size_t)qrow * rowstride + (lg + 4 * s) * 16);
+    }
   // softmax(q.k*scale) == softmax2((q*scale*log2e).k): one multiply per S element saved in the tile loop.  For exact
   // powers of two (d = 64, 256: scale = 1/8, 1/16) the product q*scale is exact in bf16/f16; log2e is applied in f32 below.
   const float sc2 = p.scale_log2e;
-  f32x4_t o[DT];
+  f32x4_t o[QT][DT];
+  float m_run[QT], l_run[QT];
 #pragma unroll
-  for (int i = 0; i < DT; ++i) o[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float m_run = -INFINITY, l_run = 0.f;
+  for (int qt = 0; qt < QT; ++qt) {
+    m_run[qt] = -INFINITY; l_run[qt] = 0.f;
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[qt][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
 
   const int ntiles = (p.t + 63) / 64;
   constexpr int NCH = (64 * CH) / 256;             // 16-byte chunks of K (and of V) staged per thread per tile
@@ -97,60 +105,70 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
     __syncthreads();
     if (kt + 1 < ntiles) { ATT_LOAD_TILE(key0 + 64); }
 
-    // ---- S^T tiles: 4 x (16 keys x 16 queries)
-    f32x4_t sacc[4];
+    // ---- S^T tiles: 4 x (16 keys x 16 queries) per query tile; a K fragment feeds every query tile
+    f32x4_t sacc[QT][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      sacc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) sacc[qt][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < KSTEPS; ++s) {
         const uint4 ka = *reinterpret_cast<const uint4*>(sK + (j * 16 + lq) * ROWB + (lg + 4 * s) * 16);
-        sacc[j] = AttMma<T>::run(ka, qf[s], sacc[j]);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) sacc[qt][j] = AttMma<T>::run(ka, qf[qt][s], sacc[qt][j]);
       }
     }
     // ---- online softmax; lane holds keys key0 + j*16 + lg*4 + r of query lq.  The running max is kept in the
     // un-scaled domain and the scale (incl. log2 e) is folded into the exponent: exp2(s*sc2 - m*sc2), one FMA per element.
-    if (key0 + 64 > p.t) {                           // only the last tile of a ragged sequence needs the mask
+    uint4 pb[QT][2];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      if (key0 + 64 > p.t) {                         // only the last tile of a ragged sequence needs the mask
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (key0 + j * 16 + lg * 4 + r >= p.t) sacc[qt][j][r] = -INFINITY;
+      }
+      float tmax = fmaxf(fmaxf(sacc[qt][0][0], sacc[qt][0][1]), fmaxf(sacc[qt][0][2], sacc[qt][0][3]));
+#pragma unroll
+      for (int j = 1; j < 4; ++j)
+        tmax = fmaxf(tmax, fmaxf(fmaxf(sacc[qt][j][0], sacc[qt][j][1]), fmaxf(sacc[qt][j][2], sacc[qt][j][3])));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m_run[qt], tmax);    // finite: every tile has >= 1 valid key
+      const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * sc2);
+      const float mb = m_new * sc2;
+      float psum = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (key0 + j * 16 + lg * 4 + r >= p.t) sacc[j][r] = -INFINITY;
-    }
-    float tmax = fmaxf(fmaxf(sacc[0][0], sacc[0][1]), fmaxf(sacc[0][2], sacc[0][3]));
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(fmaf(sacc[qt][j][r], sc2, -mb));
+          sacc[qt][j][r] = e;
+          psum += e;
+        }
+      psum += __shfl_xor(psum, 16, 64);
+      psum += __shfl_xor(psum, 32, 64);
+      l_run[qt] = l_run[qt] * alpha + psum;
+      m_run[qt] = m_new;
+      if (!__all(alpha == 1.0f)) {                   // running max unchanged for the whole wave: nothing to rescale
 #pragma unroll
-    for (int j = 1; j < 4; ++j) tmax = fmaxf(tmax, fmaxf(fmaxf(sacc[j][0], sacc[j][1]), fmaxf(sacc[j][2], sacc[j][3])));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m_run, tmax);          // finite: every tile has >= 1 valid key
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc2);
-    const float mb = m_new * sc2;
-    float psum = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = __builtin_amdgcn_exp2f(fmaf(sacc[j][r], sc2, -mb));
-        sacc[j][r] = e;
-        psum += e;
+        for (int i = 0; i < DT; ++i) o[qt][i] *= alpha;
       }
-    psum += __shfl_xor(psum, 16, 64);
-    psum += __shfl_xor(psum, 32, 64);
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-    if (!__all(alpha == 1.0f)) {                     // running max unchanged for the whole wave: nothing to rescale
+      // P^T as the B operand; k-slot (lg, e): e<4 -> key 16*(2kk) + 4lg + e ; e>=4 -> key 16*(2kk+1) + 4lg + e-4
 #pragma unroll
-      for (int i = 0; i < DT; ++i) o[i] *= alpha;
+      for (int kk = 0; kk < 2; ++kk) {
+        pb[qt][kk].x = AttMma<T>::pack2(sacc[qt][2 * kk][0], sacc[qt][2 * kk][1]);
+        pb[qt][kk].y = AttMma<T>::pack2(sacc[qt][2 * kk][2], sacc[qt][2 * kk][3]);
+        pb[qt][kk].z = AttMma<T>::pack2(sacc[qt][2 * kk + 1][0], sacc[qt][2 * kk + 1][1]);
+        pb[qt][kk].w = AttMma<T>::pack2(sacc[qt][2 * kk + 1][2], sacc[qt][2 * kk + 1][3]);
+      }
     }
 
-    // ---- O^T += V^T . P^T ; k-slot (lg, e): e<4 -> key 16*(2kk) + 4lg + e ; e>=4 -> key 16*(2kk+1) + 4lg + e-4
+    // ---- O^T += V^T . P^T ; a V^T fragment feeds every query tile
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      uint4 pb;
-      pb.x = AttMma<T>::pack2(sacc[2 * kk][0], sacc[2 * kk][1]);
-      pb.y = AttMma<T>::pack2(sacc[2 * kk][2], sacc[2 * kk][3]);
-      pb.z = AttMma<T>::pack2(sacc[2 * kk + 1][0], sacc[2 * kk + 1][1]);
-      pb.w = AttMma<T>::pack2(sacc[2 * kk + 1][2], sacc[2 * kk + 1][3]);
       // transposed read: lane 4q'+p' of each 16-lane group addresses row q', columns 4p'..4p'+3 of a 4x16 block
       const int rq = (lane & 15) >> 2, rp = lane & 3;
       const char* va = sV + (32 * kk + 4 * lg + rq) * ROWB + rp * 8;
@@ -162,20 +180,26 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
         // the two transposed 8-byte reads ARE the operand's four dwords (element-wise repacking compiled to 16 shift/or ops)
         const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi);
         const uint4 av = make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
-        o[dt] = AttMma<T>::run(av, pb, o[dt]);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) o[qt][dt] = AttMma<T>::run(av, pb[qt][kk], o[qt][dt]);
       }
     }
   }
   // ---- store: lane holds channels dt*16 + lg*4 + r of query lq
-  if (qrow < p.t) {
-    const float inv = 1.f / l_run;
-    T* orow = reinterpret_cast<T*>(p.out) + ((size_t)n * p.t + qrow) * C + head * D;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+  for (int qt = 0; qt < QT; ++qt) {
+    const int qrow = q0 + qt * 16 + lq;
+    if (qrow < p.t) {
+      const float inv = 1.f / l_run[qt];
+      T* orow = reinterpret_cast<T*>(p.out) + ((size_t)n * p.t + qrow) * C + head * D;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) st1<T>(orow + dt * 16 + lg * 4 + r, o[dt][r] * inv);
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st1<T>(orow + dt * 16 + lg * 4 + r, o[qt][dt][r] * inv);
+    }
   }
 }
+#undef ATT_LOAD_TILE
 
 // ------------------------------------------------------------------------------------------------
 // f32 (parity) path: same structure on v_mfma_f32_16x16x4_f32; V needs no transpose (one k per lane group).
@@ -287,20 +311,27 @@ __global__ __launch_bounds__(256) void attention32_kernel(const AttP p) {
 }
 
 template <typename K>
-int launch_att(K kernel, const AttP& p, size_t lds, hipStream_t st) {
+int launch_att(K kernel, const AttP& p, size_t lds, hipStream_t st, int qblock = 64) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kernel, dim3((p.t + 63) / 64, p.n * p.heads), dim3(256), lds, st, p);
+  hipLaunchKernelGGL(kernel, dim3((p.t + qblock - 1) / qblock, p.n * p.heads), dim3(256), lds, st, p);
   DTS_CHECK_LAUNCH("dts_attention");
   return DTS_OK;
 }
 
+int g_att_qt = -1;             // DTS_ATT_QT=1|2 forces the query tiles per wave (tuning aid); default: by sequence length
+
 template <typename T>
 int att16(const AttP& p, hipStream_t st) {
+  if (g_att_qt < 0) { const char* e = getenv("DTS_ATT_QT"); g_att_qt = e ? atoi(e) : 0; }
   const size_t lds = (size_t)2 * 64 * (p.d * 2 + 32);
   switch (p.d) {
-    case 64: return launch_att(attention16_kernel<T, 64>, p, lds, st);
-    case 128: return launch_att(attention16_kernel<T, 128>, p, lds, st);
-    case 256: return launch_att(attention16_kernel<T, 256>, p, lds, st);
+    case 64:
+      // two query tiles per wave once the sequence is long enough to keep >= 2 blocks per CU in the grid
+      if (g_att_qt == 2 || (g_att_qt == 0 && p.t >= 256 && (long long)((p.t + 127) / 128) * p.n * p.heads >= 512))
+        return launch_att(attention16_kernel<T, 64, 2>, p, lds, st, 128);
+      return launch_att(attention16_kernel<T, 64, 1>, p, lds, st);
+    case 128: return launch_att(attention16_kernel<T, 128, 1>, p, lds, st);
+    case 256: return launch_att(attention16_kernel<T, 256, 1>, p, lds, st);
   }
   return DTS_ERR_UNSUPPORTED;
 }
