@@ -44,31 +44,33 @@ def log(msg):
 
 
 class HipEvents:
-    """hipEvent timing on the launch stream through the HIP runtime torch already loaded.  Events are created with
-    hipEventDisableSystemFence: the default (system-scope release at every record) writes back and invalidates the L2
-    between kernels, which the un-instrumented run never does, and inflated the conv launches by 30-50 %."""
-    DISABLE_SYSTEM_FENCE = 0x20000000
+    """hipEvent pairs ATTACHED TO A KERNEL'S OWN DISPATCH (hipExtLaunchKernelGGL start/stop events, passed down through
+    dts_conv_args.ev_start/ev_stop): the timestamps are those of the kernel's packet, which is what `rocprofv3 --kernel-trace`
+    reports, with no barrier packet or fence between launches.  Events recorded around a launch from the host (even without the
+    system fence, even behind a GPU spin) read 30-50 % long on some boxes of the pool and right on others."""
 
     def __init__(self):
         import ctypes
         self.c = ctypes
         self.hip = ctypes.CDLL('libamdhip64.so')
-        self.hip.hipEventCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
-        self.hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self.hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
         self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
         self.hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
         self.live = []
 
-    def record(self):
-        ev = self.c.c_void_p()
-        assert self.hip.hipEventCreateWithFlags(self.c.byref(ev), self.DISABLE_SYSTEM_FENCE) == 0
-        assert self.hip.hipEventRecord(ev, self.c.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
-        self.live.append(ev)
-        return ev
+    def pair(self):
+        evs = []
+        for _ in range(2):
+            ev = self.c.c_void_p()
+            assert self.hip.hipEventCreate(self.c.byref(ev)) == 0
+            self.live.append(ev)
+            evs.append(ev)
+        return evs[0], evs[1]
 
     def elapsed_ms(self, a, b):
         ms = self.c.c_float()
-        assert self.hip.hipEventElapsedTime(self.c.byref(ms), a, b) == 0
+        rc = self.hip.hipEventElapsedTime(self.c.byref(ms), a, b)
+        assert rc == 0, rc
         return ms.value
 
     def close(self):
@@ -245,13 +247,8 @@ def main():
         hev = HipEvents()
 
         def timed_conv(x1, w, bias=None, **kw):
-            # keep the GPU busy while the host enqueues (e0, kernel, e1): otherwise the pair brackets the host's
-            # launch latency as well and the short kernels read long (checked against rocprofv3).  ~0.4 ms of spin:
-            # 200k cycles (~80 us) was not always enough for the Python-side enqueue on a slower host (151 vs 101 us).
-            torch.cuda._sleep(1_000_000)
-            e0 = hev.record()
-            out = orig(x1, w, bias, **kw)
-            e1 = hev.record()
+            e0, e1 = hev.pair()
+            out = orig(x1, w, bias, timing_events=(e0, e1), **kw)
             n_, ho, wo, co = out.shape
             rec.append((2.0 * n_ * ho * wo * co * w.shape[1] * w.shape[2] * w.shape[3], e0, e1,
                         (tuple(x1.shape), tuple(w.shape), 'x2' if kw.get('x2') is not None else '', 'up' if kw.get('up') else '',

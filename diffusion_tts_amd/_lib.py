@@ -21,7 +21,8 @@ class ConvArgs(C.Structure):
                 ('bias_nc', _p), ('ld_bias_nc', C.c_int32), ('residual', _p), ('out', _p),
                 ('n', C.c_int32), ('hin', C.c_int32), ('win', C.c_int32), ('cout', C.c_int32),
                 ('ksize', C.c_int32), ('up', C.c_int32), ('out_scale', C.c_float), ('dtype', C.c_int32),
-                ('workspace', _p), ('workspace_bytes', C.c_int64), ('stats_out', _p), ('stats_written', C.c_int32)]
+                ('workspace', _p), ('workspace_bytes', C.c_int64), ('stats_out', _p), ('stats_written', C.c_int32),
+                ('ev_start', _p), ('ev_stop', _p)]
 
 
 # name -> argtypes (every function returns int status except the three noted below)

@@ -21,11 +21,13 @@
 // Double-buffered: tile k+1 is in flight while tile k feeds the MFMAs.
 // f32 mode uses v_mfma_f32_16x16x4_f32 (exact f32 FMA chain) = the parity path.
 #include "dts_common.h"
+#include <hip/hip_ext.h>
 #include <type_traits>
 
 namespace {
 
 thread_local bool g_stats_written = false;
+thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;   // optional dispatch-attached timing events (dts_conv_args)
 
 struct ConvP {
   const char* x1; const char* x2;
@@ -665,7 +667,10 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<T, MT, NT, WM, WN, PF>), dim3(nblk, splits), dim3(64 * NW), lds, st, q);
+  if (g_ev_start != nullptr && g_ev_stop != nullptr)
+    hipExtLaunchKernelGGL((conv_igemm_kernel<T, MT, NT, WM, WN, PF>), dim3(nblk, splits), dim3(64 * NW), lds, st, g_ev_start, g_ev_stop, 0, q);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<T, MT, NT, WM, WN, PF>), dim3(nblk, splits), dim3(64 * NW), lds, st, q);
   DTS_CHECK_LAUNCH("dts_conv2d");
   if (splits > 1) {
     long long g = ((long long)p.P * (p.cout / 4) + 255) / 256;
@@ -738,6 +743,7 @@ extern "C" int dts_conv2d(const dts_conv_args* a, dts_stream s) {
   hipStream_t st = to_stream(s);
   int rc = DTS_OK;
   g_stats_written = false;
+  g_ev_start = (hipEvent_t)a->ev_start; g_ev_stop = (hipEvent_t)a->ev_stop;
   DTS_DISPATCH_DTYPE(a->dtype, rc = conv_dispatch<T>(p, st, (float*)a->workspace, (long long)a->workspace_bytes));
   const_cast<dts_conv_args*>(a)->stats_written = g_stats_written ? 1 : 0;
   return rc;

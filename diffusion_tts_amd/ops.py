@@ -92,8 +92,10 @@ def _conv_workspace(device):
     return ws
 
 
-def conv2d(x1, w, bias=None, *, x2=None, bias_nc=None, residual=None, up=False, out_scale=1.0, out=None, gn_stats=False):
-    """gn_stats=True: the epilogue also emits the GroupNorm moments of the output (per 64-pixel strip and channel); they
+def conv2d(x1, w, bias=None, *, x2=None, bias_nc=None, residual=None, up=False, out_scale=1.0, out=None, gn_stats=False,
+           timing_events=None):
+    """timing_events=(start, stop): raw hipEvent_t handles attached to the conv kernel's own dispatch (measurement only).
+    gn_stats=True: the epilogue also emits the GroupNorm moments of the output (per 64-pixel strip and channel); they
     ride on the returned tensor as `out._gn_stats` (None when the launch could not produce them) and are consumed by
     group_norm(), which then skips its own pass over the tensor."""
     n, hin, win, c1 = x1.shape
@@ -122,6 +124,8 @@ def conv2d(x1, w, bias=None, *, x2=None, bias_nc=None, residual=None, up=False, 
     if gn_stats and (ho * wo) % 64 == 0:
         st = torch.empty(((n * ho * wo) // 64, cout, 2), dtype=torch.float32, device=x1.device)
         a.stats_out = st.data_ptr()
+    if timing_events is not None:
+        a.ev_start, a.ev_stop = timing_events
     _call('dts_conv2d', C.byref(a))
     out._gn_stats = st if (st is not None and a.stats_written) else None
     return out
