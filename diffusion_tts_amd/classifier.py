@@ -34,6 +34,8 @@ class EncoderUNetModel:
         if not torch.cuda.is_available():
             raise RuntimeError('EncoderUNetModel (HIP) needs a GPU: there is no CPU fallback in this package')
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
+        from .graphs import GraphCache
+        self._graphs = GraphCache(self._device_forward)
         f = lambda t: t.detach().to(self.device, torch.float32).contiguous()
         sd, dt = state_dict, dtype
         mc = cfg.model_channels
@@ -102,8 +104,12 @@ class EncoderUNetModel:
     @torch.no_grad()
     def __call__(self, x, timesteps):
         """x f32 NCHW [n,3,R,R] on the GPU (values in [0,1], scorers.py:153); timesteps [n] -> logits f32 [n, K]."""
-        n = x.shape[0]
         t = timesteps.to(self.device, torch.float32).contiguous()
+        return self._graphs(x.to(self.device, torch.float32).contiguous(), t)    # HIP-graph replay of the fixed-shape forward
+
+    @torch.no_grad()
+    def _device_forward(self, x, t):
+        n = x.shape[0]
         emb = ops.pos_embedding(t, self.freqs)                                   # nn_utils.py:103-121
         emb = ops.linear(emb, self.te0_w, self.te0_b, act_out=True)
         emb = ops.linear(emb, self.te2_w, self.te2_b, act_out=True)              # SiLU of emb_layers[0], shared by all blocks

@@ -53,6 +53,8 @@ class EDMPrecond:
         self.eps = 1e-5 if self.adm else 1e-6
         self.skip_scale = 1.0 if self.adm else math.sqrt(0.5)
         self.evals = 0                               # rows pushed through the denoiser (BASELINE metric unit)
+        from .graphs import GraphCache
+        self._graphs = GraphCache(self._device_forward)     # HIP-graph replay of the fixed-shape forward (graphs.py)
         sd = {k[len('model.'):]: v for k, v in state_dict.items() if k.startswith('model.')}
         self._load(sd)
 
@@ -201,6 +203,13 @@ class EDMPrecond:
         return ops.conv_out3(h, self.out_w, self.out_cb)
 
     @torch.no_grad()
+    def _device_forward(self, x, sigma, class_labels):
+        """The fixed-shape device part of the forward (all inputs already on the GPU): what graphs.GraphCache captures."""
+        xin, coef = ops.edm_precond_in(x, sigma, self.sigma_data)
+        F = self.unet(xin, coef[:, 3].contiguous(), class_labels)
+        return ops.edm_precond_out(x, F, coef)
+
+    @torch.no_grad()
     def __call__(self, x, sigma, class_labels=None):
         """EDMPrecond.forward (networks.py:654-668)."""
         x = x.to(self.device, torch.float64).contiguous()
@@ -208,7 +217,7 @@ class EDMPrecond:
         sigma = torch.as_tensor(sigma).to(self.device, torch.float64).reshape(-1).contiguous()
         if sigma.numel() not in (1, n):
             raise ValueError(f'sigma has {sigma.numel()} entries for batch {n}')
-        xin, coef = ops.edm_precond_in(x, sigma, self.sigma_data)
-        F = self.unet(xin, coef[:, 3].contiguous(), class_labels)
+        if class_labels is not None:
+            class_labels = class_labels.to(self.device, torch.float32).contiguous()
         self.evals += n
-        return ops.edm_precond_out(x, F, coef)
+        return self._graphs(x, sigma, class_labels)

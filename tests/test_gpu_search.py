@@ -267,3 +267,22 @@ def test_bulk_generation_by_seed(pkg, manifest, tmp_path):
     import PIL.Image
     png = np.array(PIL.Image.open(tmp_path / '000000' / '000007.png'))
     assert np.array_equal(png, done[7]['image'][0].permute(1, 2, 0).numpy())
+
+
+def test_hip_graph_replay_is_bit_identical_to_eager_launches(pkg, golden, manifest):
+    """graphs.GraphCache: from the third call of a shape on, the denoiser forward is one HIP-graph launch of the very same
+    kernel sequence -- outputs must be bit-identical to the eager launches, for changing inputs."""
+    net = hip_net(pkg, manifest, 'adm_tiny', torch.bfloat16)
+    assert net._graphs.enabled
+    x = T(golden['fwd_adm_tiny_hi_x']).repeat(3, 1, 1, 1)[:5]
+    lab = T(golden['fwd_labels'])[:1].repeat(5, 1)
+    outs = []
+    for i in range(5):
+        xi, si = x * (1.0 + 0.1 * i), torch.tensor([2.0 + i])
+        got = net(xi, si, lab)
+        net._graphs.enabled = False
+        want = net(xi, si, lab)
+        net._graphs.enabled = True
+        assert torch.equal(got, want), i
+        outs.append(got)
+    assert net._graphs.replays >= 2 and not torch.equal(outs[0], outs[4])
