@@ -214,7 +214,12 @@ def main():
             dist.barrier(device_ids=[dev.index]) if dist.get_backend() == 'nccl' else dist.barrier()
         torch.cuda.synchronize(dev)
 
-    log(f'state resident; {nl} candidates on this rank; warmup')
+    # setup, not warm-up: the forwards are captured as HIP graphs on the third call of a shape (graphs.py); two untimed iterations
+    # here keep that one-off capture (~0.5 s) out of the W warm-up steps and the K timed steps whatever W is
+    for s in range(2):
+        one_step(s)
+    torch.cuda.synchronize(dev)
+    log(f'state resident; {nl} candidates on this rank; forwards captured ({net._graphs.captures} graphs); warmup')
     for s in range(a.warmup):
         one_step(s)
         torch.cuda.synchronize(dev)
