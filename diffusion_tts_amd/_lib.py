@@ -61,6 +61,7 @@ SIGNATURES = {
 OTHER = {'dts_version': ([], _i), 'dts_last_error': ([], C.c_char_p), 'dts_gn_ws_floats': ([_i, _i], _i64)}
 
 _lib = None
+ABI_VERSION = 101              # include/dts.h DTS_ABI_VERSION this binding was written against (ConvArgs = 160 bytes)
 
 
 def load():
@@ -78,6 +79,9 @@ def load():
     for name, (argt, rest) in OTHER.items():
         fn = getattr(lib, name)
         fn.argtypes, fn.restype = argt, rest
+    got = lib.dts_version()
+    if got != ABI_VERSION or C.sizeof(ConvArgs) != 160:
+        raise RuntimeError(f'{LIB_PATH} has ABI version {got}, this binding needs {ABI_VERSION}: rebuild with `python -m diffusion_tts_amd.build --force`')
     _lib = lib
     return lib
 

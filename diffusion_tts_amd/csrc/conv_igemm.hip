@@ -24,6 +24,8 @@
 #include <hip/hip_ext.h>
 #include <type_traits>
 
+static_assert(sizeof(dts_conv_args) == 160, "dts_conv_args layout changed: bump DTS_ABI_VERSION and update the bindings (_lib.py ConvArgs)");
+
 namespace {
 
 thread_local bool g_stats_written = false;

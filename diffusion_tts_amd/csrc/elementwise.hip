@@ -14,7 +14,7 @@ void dts_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* dts_last_error(void) { return g_err; }
-extern "C" int dts_version(void) { return 100; }
+extern "C" int dts_version(void) { return DTS_ABI_VERSION; }
 
 namespace {
 

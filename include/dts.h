@@ -30,7 +30,8 @@ typedef void* dts_stream;
 enum dts_dtype { DTS_F32 = 0, DTS_BF16 = 1, DTS_F16 = 2 };
 enum dts_status { DTS_OK = 0, DTS_ERR_ARG = -1, DTS_ERR_LAUNCH = -2, DTS_ERR_UNSUPPORTED = -3 };
 
-int dts_version(void);
+#define DTS_ABI_VERSION 101        /* bumped with every change of a signature or of dts_conv_args (101: ev_start/ev_stop) */
+int dts_version(void);            /* == DTS_ABI_VERSION of the build; a binding must refuse any other value */
 const char* dts_last_error(void);
 
 /* ---- layout / packing (weight preparation and test plumbing; not on the per-step path) ------------ */

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f'{s} declared in include/dts.h but not exported'
     bound = set(_lib.SIGNATURES) | set(_lib.OTHER)
     assert bound == set(syms), (bound ^ set(syms))
-    assert _lib.load().dts_version() >= 100
+    assert _lib.load().dts_version() == _lib.ABI_VERSION
 
 
 def test_product_never_imports_the_oracle():
