@@ -20,13 +20,13 @@ template <> struct AttMma<bf16_t> {
   static __device__ __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
   }
-  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16); }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack2_bf16(lo, hi); }
 };
 template <> struct AttMma<f16_t> {
   static __device__ __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
   }
-  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return f32_to_f16_bits(lo) | (f32_to_f16_bits(hi) << 16); }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack2_f16(lo, hi); }
 };
 
 struct AttP {

@@ -92,7 +92,7 @@ template <> struct Vec4<float> {
 template <> struct Vec4<bf16_t> {
   using type = uint2;
   static __device__ __forceinline__ uint2 pack(const float* f) {
-    return make_uint2(f32_to_bf16_bits(f[0]) | (f32_to_bf16_bits(f[1]) << 16), f32_to_bf16_bits(f[2]) | (f32_to_bf16_bits(f[3]) << 16));
+    return make_uint2(pack2_bf16(f[0], f[1]), pack2_bf16(f[2], f[3]));
   }
   static __device__ __forceinline__ void unpack(const uint2& v, float* f) {
     f[0] = bf16_bits_to_f32(v.x & 0xffffu); f[1] = bf16_bits_to_f32(v.x >> 16);
@@ -104,14 +104,13 @@ template <> struct Vec4<bf16_t> {
     f[2] = bf16_bits_to_f32(v.y & 0xffffu); f[3] = bf16_bits_to_f32(v.y >> 16);
   }
   static __device__ __forceinline__ void store(bf16_t* p, const float* f) {
-    *reinterpret_cast<uint2*>(p) = make_uint2(f32_to_bf16_bits(f[0]) | (f32_to_bf16_bits(f[1]) << 16),
-                                              f32_to_bf16_bits(f[2]) | (f32_to_bf16_bits(f[3]) << 16));
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack2_bf16(f[0], f[1]), pack2_bf16(f[2], f[3]));
   }
 };
 template <> struct Vec4<f16_t> {
   using type = uint2;
   static __device__ __forceinline__ uint2 pack(const float* f) {
-    return make_uint2(f32_to_f16_bits(f[0]) | (f32_to_f16_bits(f[1]) << 16), f32_to_f16_bits(f[2]) | (f32_to_f16_bits(f[3]) << 16));
+    return make_uint2(pack2_f16(f[0], f[1]), pack2_f16(f[2], f[3]));
   }
   static __device__ __forceinline__ void unpack(const uint2& v, float* f) {
     f[0] = f16_bits_to_f32(v.x & 0xffffu); f[1] = f16_bits_to_f32(v.x >> 16);
@@ -123,8 +122,7 @@ template <> struct Vec4<f16_t> {
     f[2] = f16_bits_to_f32(v.y & 0xffffu); f[3] = f16_bits_to_f32(v.y >> 16);
   }
   static __device__ __forceinline__ void store(f16_t* p, const float* f) {
-    *reinterpret_cast<uint2*>(p) = make_uint2(f32_to_f16_bits(f[0]) | (f32_to_f16_bits(f[1]) << 16),
-                                              f32_to_f16_bits(f[2]) | (f32_to_f16_bits(f[3]) << 16));
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack2_f16(f[0], f[1]), pack2_f16(f[2], f[3]));
   }
 };
 

@@ -55,6 +55,20 @@ __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
   __bf16 h = (__bf16)f;  // RNE, NaN-preserving (v_cvt_pk_bf16_f32)
   return (uint32_t)__builtin_bit_cast(uint16_t, h);
 }
+// two floats -> one dword of two 16-bit values, ONE instruction (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32, RNE like the scalar
+// conversions above).  Converting the halves separately and merging them costs 4 VALU instructions per pair, which was a
+// quarter of the conv epilogue's arithmetic and of the attention loop's P packing.
+typedef __bf16 dts_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 dts_f16x2_t __attribute__((ext_vector_type(2)));
+typedef float dts_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+  const dts_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, dts_bf16x2_t));
+}
+__device__ __forceinline__ uint32_t pack2_f16(float lo, float hi) {
+  const dts_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, dts_f16x2_t));
+}
 __device__ __forceinline__ float f16_bits_to_f32(uint32_t b) {
   return (float)__builtin_bit_cast(_Float16, (uint16_t)b);
 }
@@ -96,16 +110,10 @@ template <> __device__ __forceinline__ uint4 pack16<float>(const float* f) {
                     __builtin_bit_cast(uint32_t, f[2]), __builtin_bit_cast(uint32_t, f[3]));
 }
 template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* f) {
-  return make_uint4(f32_to_bf16_bits(f[0]) | (f32_to_bf16_bits(f[1]) << 16),
-                    f32_to_bf16_bits(f[2]) | (f32_to_bf16_bits(f[3]) << 16),
-                    f32_to_bf16_bits(f[4]) | (f32_to_bf16_bits(f[5]) << 16),
-                    f32_to_bf16_bits(f[6]) | (f32_to_bf16_bits(f[7]) << 16));
+  return make_uint4(pack2_bf16(f[0], f[1]), pack2_bf16(f[2], f[3]), pack2_bf16(f[4], f[5]), pack2_bf16(f[6], f[7]));
 }
 template <> __device__ __forceinline__ uint4 pack16<f16_t>(const float* f) {
-  return make_uint4(f32_to_f16_bits(f[0]) | (f32_to_f16_bits(f[1]) << 16),
-                    f32_to_f16_bits(f[2]) | (f32_to_f16_bits(f[3]) << 16),
-                    f32_to_f16_bits(f[4]) | (f32_to_f16_bits(f[5]) << 16),
-                    f32_to_f16_bits(f[6]) | (f32_to_f16_bits(f[7]) << 16));
+  return make_uint4(pack2_f16(f[0], f[1]), pack2_f16(f[2], f[3]), pack2_f16(f[4], f[5]), pack2_f16(f[6], f[7]));
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }

@@ -249,7 +249,7 @@ template <> struct Pair<bf16_t> {
     const uint32_t v = *reinterpret_cast<const uint32_t*>(p); a = bf16_bits_to_f32(v & 0xffffu); b = bf16_bits_to_f32(v >> 16);
   }
   static __device__ __forceinline__ void store(bf16_t* p, float a, float b) {
-    *reinterpret_cast<uint32_t*>(p) = f32_to_bf16_bits(a) | (f32_to_bf16_bits(b) << 16);
+    *reinterpret_cast<uint32_t*>(p) = pack2_bf16(a, b);
   }
 };
 template <> struct Pair<f16_t> {
@@ -257,7 +257,7 @@ template <> struct Pair<f16_t> {
     const uint32_t v = *reinterpret_cast<const uint32_t*>(p); a = f16_bits_to_f32(v & 0xffffu); b = f16_bits_to_f32(v >> 16);
   }
   static __device__ __forceinline__ void store(f16_t* p, float a, float b) {
-    *reinterpret_cast<uint32_t*>(p) = f32_to_f16_bits(a) | (f32_to_f16_bits(b) << 16);
+    *reinterpret_cast<uint32_t*>(p) = pack2_f16(a, b);
   }
 };
 
