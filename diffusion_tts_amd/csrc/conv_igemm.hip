@@ -454,30 +454,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
   const int wm = wid % WM, wn = wid / WM;
   const int chunk = tid & 7, r0 = tid >> 3;          // staging: 16-byte chunk, first row
 
-  // ---- per-thread pixel rows of the B tile (fixed for the whole K loop)
   int pix_n[RB], pix_hw[RB];
-#pragma unroll
-  for (int j = 0; j < RB; ++j) {
-    const int pp = pn0 + r0 + SLAB * j;
-    if (pp < p_P) {
-      int n, ho, wo;
-      if (kp.hw_shift >= 0) {                            // block-uniform: every U-Net level here is a power of two
-        n = pp >> kp.hw_shift;
-        const int rem = pp & ((1 << kp.hw_shift) - 1);
-        ho = rem >> kp.w_shift; wo = rem & ((1 << kp.w_shift) - 1);
-      } else {
-        const int hw = p_hout * p_wout;
-        n = pp / hw;
-        const int rem = pp - n * hw;
-        ho = rem / p_wout; wo = rem - ho * p_wout;
-      }
-      pix_n[j] = n * p_hin * p_win;
-      pix_hw[j] = (ho << 16) | wo;
-    } else {
-      pix_n[j] = -1;
-      pix_hw[j] = 0;
-    }
-  }
   const int K = p_taps * p_cin;
   const int steps_per_tap = p_cin / BKE;
   const int nk_all = p_taps * steps_per_tap;
@@ -541,8 +518,40 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
   int tap = ks_begin / steps_per_tap, ci0 = (ks_begin - tap * steps_per_tap) * BKE;
 #pragma unroll
   for (int j = 0; j < RA; ++j) arow[j] = p_w + ((size_t)(cm0 + r0 + SLAB * j) * K + (size_t)ks_begin * BKE) * ES + schunk;
+  // first tile: the weight rows go out before the pixel coordinates of the activation rows are worked out, so that
+  // arithmetic runs under the first loads' latency (the prologue is ~5k exposed cycles per block)
+  {
+    const uint32_t sa_ = wave_rows;
+    _Pragma("unroll") for (int j = 0; j < RA; ++j) glds16(arow[j], sa_ + j * SLAB * 128);
+  }
+  // ---- per-thread pixel rows of the B tile (fixed for the whole K loop)
+#pragma unroll
+  for (int j = 0; j < RB; ++j) {
+    const int pp = pn0 + r0 + SLAB * j;
+    if (pp < p_P) {
+      int n, ho, wo;
+      if (kp.hw_shift >= 0) {                            // block-uniform: every U-Net level here is a power of two
+        n = pp >> kp.hw_shift;
+        const int rem = pp & ((1 << kp.hw_shift) - 1);
+        ho = rem >> kp.w_shift; wo = rem & ((1 << kp.w_shift) - 1);
+      } else {
+        const int hw = p_hout * p_wout;
+        n = pp / hw;
+        const int rem = pp - n * hw;
+        ho = rem / p_wout; wo = rem - ho * p_wout;
+      }
+      pix_n[j] = n * p_hin * p_win;
+      pix_hw[j] = (ho << 16) | wo;
+    } else {
+      pix_n[j] = -1;
+      pix_hw[j] = 0;
+    }
+  }
   SET_ROWS(tap, ci0);
-  ISSUE_TILE(0);
+  {
+    const uint32_t sb_ = wave_rows + A_BYTES;
+    _Pragma("unroll") for (int j = 0; j < RB; ++j) glds16(brow[j], sb_ + j * SLAB * 128);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
