@@ -141,6 +141,15 @@ __device__ __forceinline__ void glds16(const char* g, uint32_t lds_off) {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
+// sum over the 16 lanes of a DPP row (fixed order; every lane ends with the total)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));   // row_mirror
+  return v;
+}
+
 // ---- epilogue fast path: 16-bit output, whole pixel tile inside the image batch (always, for the U-Net levels at the batch sizes
 // of the search loop).  No per-lane predication, every global/LDS address is one base per nt plus compile-time offsets:
 // the generic epilogue below executes ~1.5k instructions per wave (a predicated branch per access, a 64-bit address per
@@ -246,11 +255,10 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
       }
     }
     if constexpr (want_stats) {
+      // 16-lane (pixel) reduction on DPP row operations -- quad swaps, half-row mirror, row mirror: four v_add_f32_dpp per
+      // value, no LDS crossbar (__shfl_xor is a ds_bpermute here: 192 of them per wave and tile, plus their waits)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { ss4[r] += __shfl_xor(ss4[r], o, 64); sq4[r] += __shfl_xor(sq4[r], o, 64); }
-      }
+      for (int r = 0; r < 4; ++r) { ss4[r] = row16_sum(ss4[r]); sq4[r] = row16_sum(sq4[r]); }
       if (lrow == 0) {
         float4* d = reinterpret_cast<float4*>(sp + mt * 32);
         d[0] = make_float4(ss4[0], sq4[0], ss4[1], sq4[1]);

@@ -21,6 +21,7 @@ def main():
     ap.add_argument('--n', type=int, default=64)
     ap.add_argument('--dtype', default='bf16')
     ap.add_argument('--iters', type=int, default=10)
+    ap.add_argument('--stats', action='store_true', help='also emit the fused GroupNorm strip statistics (as the network does)')
     a = ap.parse_args()
     dt = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[a.dtype]
     dev = 'cuda'
@@ -32,13 +33,13 @@ def main():
         res = torch.randn(a.n, r, r, cout, device=dev).to(dt)
         out = torch.empty(a.n, r, r, cout, device=dev, dtype=dt)
         for _ in range(2):
-            ops.conv2d(x, w, b, residual=res, out=out)
+            ops.conv2d(x, w, b, residual=res, out=out, gn_stats=a.stats)
         ts = []
         for _ in range(a.iters):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda._sleep(200_000)
             e0.record()
-            ops.conv2d(x, w, b, residual=res, out=out)
+            ops.conv2d(x, w, b, residual=res, out=out, gn_stats=a.stats)
             e1.record()
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1))
