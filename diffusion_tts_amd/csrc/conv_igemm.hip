@@ -141,6 +141,20 @@ __device__ __forceinline__ void glds16(const char* g, uint32_t lds_off) {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
+// LDS-DMA pieces [u0, u1) of the residual tile into the staged tile at LDS byte address `stage` (wave-uniform): piece u is the
+// 16-byte slots u*NTHR .. u*NTHR+NTHR-1 of the dense, XOR-swizzled pixel-major tile described in conv_epilogue_fast.
+template <int BM, int NTHR>
+__device__ __forceinline__ void issue_residual_pieces(const ConvP& kp, int cm0, int pn0, uint32_t stage, int tid, int u0, int u1) {
+  constexpr int CPR = BM / 8;
+  const char* resb = kp.residual + ((size_t)pn0 * kp.cout + cm0) * 2;
+  const size_t rstride = (size_t)kp.cout * 2;
+  const uint32_t wave_dst = __builtin_amdgcn_readfirstlane(stage + (tid >> 6) * 1024);
+  for (int u = u0; u < u1; ++u) {
+    const int slot = u * NTHR + tid, row = slot / CPR, c = slot - row * CPR;
+    glds16(resb + row * rstride + ((c ^ (row & 7)) << 4), wave_dst + u * (NTHR * 16));
+  }
+}
+
 // sum over the 16 lanes of a DPP row (fixed order; every lane ends with the total)
 __device__ __forceinline__ float row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
@@ -157,7 +171,9 @@ __device__ __forceinline__ float row16_sum(float v) {
 // Arithmetic and its order are the generic path's: ((acc + bias) + bias_nc + residual) * out_scale, rounded once.
 template <typename T, int MT, int NT, int BM, int BN, bool RES, bool BNC, bool STATS>
 __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&acc)[MT][NT], int cm0, int pn0, int wm, int wn, int lrow,
-                                                   int lq, char* smem, bool bias_in_acc) {
+                                                   int lq, char* smem_ring, bool bias_in_acc, int stage_off, int early_u0,
+                                                   int early_u1) {
+  char* smem = smem_ring + stage_off;                    // staged tile: placed so that the early residual pieces fit the free buffer
   using V4 = typename Vec4<T>::type;
   // Staged tile in the idle LDS ring: pixel-major rows of BM*2 bytes, dense (LDS-DMA writes 1 KiB contiguous per
   // wave-instruction, so no padding is possible); the 16-byte chunk c of row r sits at chunk slot c ^ (r & 7), which keeps
@@ -172,17 +188,12 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
   const int tid = threadIdx.x;
   if constexpr (RES) {
     // residual tile -> LDS by LDS-DMA, whole rows, 16 bytes per lane (the accumulator-layout loads it replaces were 24
-    // scattered 8-byte reads per lane: ~8k cycles per block by the in-kernel stamps)
-    const char* resb = kp.residual + ((size_t)pn0 * p_cout + cm0) * 2;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const uint32_t wave_dst = __builtin_amdgcn_readfirstlane(lds0 + (tid >> 6) * 1024);
-    int row = tid / CPR, c = tid - row * CPR;
-#pragma unroll
-    for (int u = 0; u < ITERS; ++u) {
-      glds16(resb + row * rstride + ((c ^ (row & 7)) << 4), wave_dst + u * 4096);
-      row += DR; c += DC;
-      if (c >= CPR) { c -= CPR; ++row; }
-    }
+    // scattered 8-byte reads per lane: ~8k cycles per block by the in-kernel stamps).  The pieces [early_u0, early_u1) were
+    // already issued during the last K step into the ring buffer that step did not read (and are complete: that step's
+    // vmcnt(0) + barrier covered them); only the rest is fetched here.
+    const uint32_t stage = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    issue_residual_pieces<BM, 256>(kp, cm0, pn0, stage, tid, 0, early_u0);
+    issue_residual_pieces<BM, 256>(kp, cm0, pn0, stage, tid, early_u1, ITERS);
   }
   float4 bv[MT];
 #pragma unroll
@@ -211,8 +222,10 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
   for (int mt = 0; mt < MT; ++mt) coff[mt] = (((wm * 2 * MT + 2 * mt + (lq >> 1)) ^ (lrow & 7)) << 4);
   const float osc = kp.out_scale;
   if constexpr (RES) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (early_u0 > 0 || early_u1 < ITERS) {            // block-uniform: some pieces were fetched just now
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
   }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -283,7 +296,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
 // ---- epilogue of one (cout tile, pixel tile[, K split]): lane holds couts co..co+3 of pixel pp for each (mt, nt)
 template <typename T, int MT, int NT, int BM, int BN>
 __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT][NT], int cm0, int pn0, int split, int wm, int wn,
-                                              int lrow, int lq, char* smem, bool bias_in_acc) {
+                                              int lrow, int lq, char* smem, bool bias_in_acc, int stage_off, int early_u0, int early_u1) {
   const int p_P = kp.P, p_cout = kp.cout, p_hout = kp.hout, p_wout = kp.wout;
   // ---- epilogue: lane holds couts co..co+3 of pixel pp for each (mt, nt): one 4-element vector load/store
   if (kp.splits > 1) {
@@ -304,7 +317,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
   if constexpr (sizeof(T) == 2) {
     if (pn0 + BN <= p_P) {                             // block-uniform
       const bool r_ = kp.residual != nullptr, b_ = kp.bias_nc != nullptr, s_ = NT == 4 && kp.stats != nullptr;
-#define DTS_EPI(R_, B_, S_) conv_epilogue_fast<T, MT, NT, BM, BN, R_, B_, S_>(kp, acc, cm0, pn0, wm, wn, lrow, lq, smem, bias_in_acc)
+#define DTS_EPI(R_, B_, S_) conv_epilogue_fast<T, MT, NT, BM, BN, R_, B_, S_>(kp, acc, cm0, pn0, wm, wn, lrow, lq, smem, bias_in_acc, stage_off, early_u0, early_u1)
       if (r_) { if (b_) { if (s_) DTS_EPI(true, true, true); else DTS_EPI(true, true, false); }
                 else    { if (s_) DTS_EPI(true, false, true); else DTS_EPI(true, false, false); } }
       else    { if (b_) { if (s_) DTS_EPI(false, true, true); else DTS_EPI(false, true, false); }
@@ -564,6 +577,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
   __syncthreads();
 
   const int lrow = lane & 15, lq = lane >> 4;
+  // early residual fetch (whole 16-bit tiles only: the ones that take conv_epilogue_fast)
+  constexpr int RING_BYTES = STAGES * STAGE_BYTES, STAGED_BYTES = BN * BM * 2, PIECE = 64 * NW * 16, PIECES = STAGED_BYTES / PIECE;
+  static_assert(STAGED_BYTES % PIECE == 0 && STAGED_BYTES <= RING_BYTES, "staged tile pieces");
+  const bool res_early = sizeof(T) == 2 && kp.residual != nullptr && kp.splits == 1 && pn0 + BN <= p_P;
+  int stage_off = 0, early_u0 = 0, early_u1 = 0;
   int buf = 0;
   for (int ks = ks_begin; ks < ks_end; ++ks) {
     const char* sa = smem + buf * STAGE_BYTES + (wm * 16 * MT) * 128;
@@ -585,6 +603,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
     if (ks + 1 < ks_end) {
       ADVANCE_K();
       ISSUE_TILE(buf ^ 1);
+    } else if (res_early) {
+      // last K step: nothing left to prefetch, so the free ring buffer takes the residual pieces that fit it; they land
+      // under this step's MFMAs instead of an exposed fetch in the epilogue
+      stage_off = (buf ^ 1) == 0 ? 0 : (RING_BYTES - STAGED_BYTES);
+      const int free_lo = (buf ^ 1) * STAGE_BYTES - stage_off;                 // free buffer in staged-tile coordinates
+      early_u0 = max(0, (free_lo + PIECE - 1) / PIECE);
+      early_u1 = min(PIECES, (free_lo + STAGE_BYTES) / PIECE);
+      issue_residual_pieces<BM, 64 * NW>(kp, cm0, pn0, lds_base + stage_off, tid, early_u0, early_u1);
     }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -611,7 +637,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
     buf ^= 1;
   }
 
-  conv_epilogue<T, MT, NT, BM, BN>(kp, acc, cm0, pn0, (int)blockIdx.y, wm, wn, lrow, lq, smem, bias_in_acc);
+  conv_epilogue<T, MT, NT, BM, BN>(kp, acc, cm0, pn0, (int)blockIdx.y, wm, wn, lrow, lq, smem, bias_in_acc, stage_off, early_u0, early_u1);
 }
 #undef SET_ROWS
 #undef ISSUE_TILE
