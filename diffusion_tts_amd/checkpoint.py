@@ -8,7 +8,8 @@ to a call `torch_utils.persistence._reconstruct_persistent_obj(meta)` with
 The reference rebuilds the classes by `exec(meta.module_src)`.  This reader never does: the reconstruct call is mapped to
 a stub that keeps `class_name` and `state`, the module tree is walked through the standard `torch.nn.Module` state
 (`_parameters`, `_buffers`, `_modules`), and the result is the (EDMConfig, state_dict) pair `networks.EDMPrecond` takes,
-with the reference's own state-dict key names.  Unknown globals in the pickle are refused (no arbitrary code).
+with the reference's own state-dict key names.  Globals are resolved through an exact (module, name) allow-list of data constructors; everything else is refused, and the
+nested storage bytes are read by torch's restricted (`weights_only`) loader.
 
 Scope = the hot path's nets: EDMPrecond over DhariwalUNet (ADM) or SongUNet with the DDPM++
 options; VP/VE/iDDPM preconditioners and NCSN++ options raise NotImplementedError.
@@ -50,22 +51,68 @@ class EasyDict(dict):
         self[name] = value
 
 
-_SAFE_BUILTINS = {'set', 'frozenset', 'dict', 'list', 'tuple', 'slice', 'complex', 'bytearray', 'object', 'int', 'float', 'bool',
-                  'str', 'bytes', 'range', 'getattr'}
-_SAFE_PREFIXES = ('torch', 'numpy', 'collections', 'copyreg', '_codecs')
+def _safe_storage_from_bytes(b):
+    """Stand-in for `torch.storage._load_from_bytes`, which is `torch.load(..., weights_only=False)` -- a second, unrestricted
+    unpickle of bytes taken from the file.  Tensor storages are plain data: torch's own restricted loader reads them."""
+    return torch.load(io.BytesIO(b), weights_only=True)
+
+
+def _allowed_globals():
+    """EXACT (module, name) pairs an EDM network pickle needs (listed from reference-written pickles, tests/golden/check_pkl_loader.py):
+    tensor / parameter rebuilders, storage classes, the two stock containers, OrderedDict, numpy scalars/arrays (the training
+    loop's bookkeeping entries).  A prefix rule ("anything under torch.*") is NOT safe: `torch.utils.collect_env.run`,
+    `torch.load`, `torch.hub.load`, `numpy.load` ... all execute or unpickle attacker-chosen input."""
+    import collections as _c
+    import numpy as _np
+    import torch._utils as _tu
+    ok = {
+        ('collections', 'OrderedDict'): _c.OrderedDict,
+        ('torch._utils', '_rebuild_tensor_v2'): _tu._rebuild_tensor_v2,
+        ('torch._utils', '_rebuild_parameter'): _tu._rebuild_parameter,
+        ('torch.storage', '_load_from_bytes'): _safe_storage_from_bytes,
+        ('torch', 'Size'): torch.Size,
+        ('torch', 'device'): torch.device,
+        ('torch.nn.modules.container', 'ModuleList'): torch.nn.ModuleList,
+        ('torch.nn.modules.container', 'ModuleDict'): torch.nn.ModuleDict,
+        ('numpy', 'ndarray'): _np.ndarray,
+        ('numpy', 'dtype'): _np.dtype,
+        ('_codecs', 'encode'): __import__('_codecs').encode,
+    }
+    for name in ('FloatStorage', 'HalfStorage', 'BFloat16Storage', 'DoubleStorage', 'LongStorage', 'IntStorage', 'ShortStorage',
+                 'CharStorage', 'ByteStorage', 'BoolStorage'):
+        ok[('torch', name)] = getattr(torch, name)
+    for name in ('float32', 'float16', 'bfloat16', 'float64', 'int64', 'int32', 'int16', 'int8', 'uint8', 'bool'):
+        ok[('torch', name)] = getattr(torch, name)
+    try:                                               # numpy >= 2 pickles through numpy._core, older files name numpy.core
+        from numpy._core import multiarray as _ma
+    except Exception:                                  # pragma: no cover
+        from numpy.core import multiarray as _ma
+    for mod in ('numpy.core.multiarray', 'numpy._core.multiarray'):
+        ok[(mod, '_reconstruct')] = _ma._reconstruct
+        ok[(mod, 'scalar')] = _ma.scalar
+    return ok
+
+
+_SAFE_BUILTINS = {'set', 'frozenset', 'dict', 'list', 'tuple', 'slice', 'complex', 'bytearray', 'int', 'float', 'bool', 'str',
+                  'bytes', 'range'}                   # constructors of plain data only (no getattr / eval / object)
+_ALLOWED = None
 
 
 class _Unpickler(pickle.Unpickler):
     def find_class(self, module, name):
+        global _ALLOWED
         if (module, name) == ('torch_utils.persistence', '_reconstruct_persistent_obj'):
             return Persisted
         if (module, name) == ('dnnlib.util', 'EasyDict'):
             return EasyDict
-        if module == 'builtins' and name in _SAFE_BUILTINS and name != 'getattr':
-            return super().find_class(module, name)
-        if module.split('.')[0] in _SAFE_PREFIXES:
-            return super().find_class(module, name)
-        raise pickle.UnpicklingError(f'global {module}.{name} is not allowed in an EDM network pickle')
+        if module == 'builtins' and name in _SAFE_BUILTINS:
+            return getattr(__import__('builtins'), name)
+        if _ALLOWED is None:
+            _ALLOWED = _allowed_globals()
+        try:
+            return _ALLOWED[(module, name)]
+        except KeyError:
+            raise pickle.UnpicklingError(f'global {module}.{name} is not allowed in an EDM network pickle') from None
 
 
 def _module_state(obj) -> Dict[str, Any]:

@@ -38,3 +38,42 @@ def test_reader_refuses_foreign_globals_and_other_preconditioners(manifest):
     cfg, sd = tiny_edm(manifest, 'adm_tiny')
     with pytest.raises(NotImplementedError):                       # VP/VE/iDDPM preconditioners are off the search path
         load_edm_pickle(synthetic_edm_pickle(cfg, sd, precond='VPPrecond'))
+
+
+class _Call:
+    """Pickles as a call of `fn(*args)` -- what a hostile network pickle would carry."""
+
+    def __init__(self, fn, *args):
+        self.fn, self.args = fn, args
+
+    def __reduce__(self):
+        return (self.fn, self.args)
+
+
+@pytest.mark.parametrize('make', [
+    lambda: _Call(__import__('torch.utils.collect_env', fromlist=['run']).run, 'echo PWNED'),     # shell command
+    lambda: _Call(torch.load, '/nonexistent'),                                                     # nested full unpickle
+    lambda: _Call(torch.hub.load, 'x', 'y'),
+    lambda: _Call(__import__('numpy').load, '/nonexistent'),
+    lambda: _Call(getattr, 'x', 'upper'),
+    lambda: _Call(eval, '1+1'),
+])
+def test_reader_resolves_globals_by_exact_allow_list(make):
+    """a prefix rule let `torch.utils.collect_env.run('echo PWNED')` execute.  Every global outside the exact
+    allow-list of data constructors must raise before anything is called."""
+    evil = pickle.dumps(dict(ema=make()))
+    with pytest.raises(pickle.UnpicklingError):
+        load_edm_pickle(evil)
+
+
+def test_nested_storage_bytes_go_through_the_restricted_loader():
+    """`torch.storage._load_from_bytes` is a plain `torch.load(weights_only=False)`; the reader substitutes torch's restricted
+    loader, so a storage blob that itself carries a foreign global is refused too."""
+    import io
+    from diffusion_tts_amd import checkpoint as ck
+    good = io.BytesIO()
+    blob = pickle.dumps(torch.arange(4.))              # a plain-pickled tensor carries its storage as such bytes
+    got = ck._Unpickler(io.BytesIO(pickle.dumps(dict(t=torch.arange(4.))))).load()['t']
+    assert torch.equal(got, torch.arange(4.)) and blob
+    with pytest.raises(Exception):
+        ck._safe_storage_from_bytes(pickle.dumps(_Call(os.getcwd)))
