@@ -58,10 +58,10 @@ SIGNATURES = {
     'dts_cfg_combine': [_p, _p, _f, _p, _i, _i64, _p],
     'dts_ddim_candidates': [_p, _p, _p, _p, _p, _i, _f, _f, _f, _i, _i64, _p],
 }
-OTHER = {'dts_version': ([], _i), 'dts_last_error': ([], C.c_char_p), 'dts_gn_ws_floats': ([_i, _i], _i64)}
+OTHER = {'dts_version': ([], _i), 'dts_set_tuning': ([_i, _i], _i), 'dts_get_tuning': ([_i], _i), 'dts_last_error': ([], C.c_char_p), 'dts_gn_ws_floats': ([_i, _i], _i64)}
 
 _lib = None
-ABI_VERSION = 101              # include/dts.h DTS_ABI_VERSION this binding was written against (ConvArgs = 160 bytes)
+ABI_VERSION = 102              # include/dts.h DTS_ABI_VERSION this binding was written against (ConvArgs = 160 bytes)
 
 
 def load():
@@ -90,3 +90,11 @@ def check(status, what=''):
     if status != 0:
         msg = load().dts_last_error().decode(errors='replace')
         raise RuntimeError(f'libdts_hip {what} failed ({status}): {msg}')
+
+
+KNOBS = {'att_xcd': 0, 'att_qt': 1, 'conv_tile': 2, 'conv_splits': 3, 'conv_variant': 4, 'gn_fuse': 5}
+
+
+def set_tuning(name, value):
+    """Measurement aid (tools/*_bench.py): switch a kernel variant / block order at run time; -1 restores the default."""
+    check(load().dts_set_tuning(KNOBS[name], int(value)), 'dts_set_tuning')

@@ -12,6 +12,8 @@
 //   O^T[d][q]  += V^T . P^T      A = V^T via transposed LDS reads, B = P straight from the S^T accumulators
 // so P never leaves registers and each lane ends up with 4 consecutive channels of its query (vector store).
 #include "dts_common.h"
+#include <mutex>
+#include <unordered_map>
 
 namespace {
 
@@ -33,7 +35,25 @@ struct AttP {
   const char* qkv; char* out;
   int n, t, heads, d;
   float scale_log2e;
+  int qblocks;                   // query blocks per (sample, head)
+  int xcd_remap;                 // 1: XCD-aware block order (default); 0: plain order (A/B aid, DTS_ATT_XCD=0)
 };
+
+// Block order.  The grid is 1-D over (sample*head, query block), (sample, head)-major.  Hardware deals consecutive block ids
+// round-robin over the 8 XCDs, each with a private 4 MB L2: in plain order the query blocks of one (sample, head) land on 8
+// different XCDs and every L2 fetches that head's K and V again (rocprofv3: 472 MB per launch against ~200 MB algorithmic at
+// T=1024, the kernel ran fabric-bound).  Remapped, the ids b, b+8, b+16.. that share an XCD walk a CONTIGUOUS range of the
+// (sample, head)-major order, so all query blocks of a head run back to back on one XCD and K/V are fetched once.
+// Bijective for any grid size (conv_igemm.hip uses the same map); placement only changes speed, never results.
+__device__ __forceinline__ void att_block(const AttP& p, int& nh, int& qb) {
+  int bid = blockIdx.x;
+  if (p.xcd_remap) {
+    const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, j = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  nh = bid / p.qblocks;
+  qb = bid - nh * p.qblocks;
+}
 
 // ------------------------------------------------------------------------------------------------
 // 16-bit element types
@@ -50,11 +70,13 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
   char* sV = smem + 64 * ROWB;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lq = lane & 15, lg = lane >> 4;
-  const int nh = blockIdx.y, n = nh / p.heads, head = nh - n * p.heads;
+  int nh, qblk;
+  att_block(p, nh, qblk);
+  const int n = nh / p.heads, head = nh - n * p.heads;
   const int C = p.heads * D;
   const size_t rowstride = (size_t)3 * C * ES;
   const char* base = p.qkv + (size_t)n * p.t * rowstride + (size_t)head * D * ES;
-  const int q0 = blockIdx.x * (64 * QT) + wid * (16 * QT);
+  const int q0 = qblk * (64 * QT) + wid * (16 * QT);
 
   // Q fragments: B operand, lane holds Q[q][8*(lg + 4s) .. +8]
   uint4 qf[QT][KSTEPS];
@@ -214,11 +236,13 @@ __global__ __launch_bounds__(256) void attention32_kernel(const AttP p) {
   char* sV = smem + 64 * ROWB;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lq = lane & 15, lg = lane >> 4;
-  const int nh = blockIdx.y, n = nh / p.heads, head = nh - n * p.heads;
+  int nh, qblk;
+  att_block(p, nh, qblk);
+  const int n = nh / p.heads, head = nh - n * p.heads;
   const int C = p.heads * D;
   const size_t rowstride = (size_t)3 * C * ES;
   const char* base = p.qkv + (size_t)n * p.t * rowstride + (size_t)head * D * ES;
-  const int q0 = blockIdx.x * 64 + wid * 16;
+  const int q0 = qblk * 64 + wid * 16;
   const int qrow = q0 + lq;
 
   f32x4_t o[DT];
@@ -311,18 +335,30 @@ __global__ __launch_bounds__(256) void attention32_kernel(const AttP p) {
 }
 
 template <typename K>
-int launch_att(K kernel, const AttP& p, size_t lds, hipStream_t st, int qblock = 64) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kernel, dim3((p.t + qblock - 1) / qblock, p.n * p.heads), dim3(256), lds, st, p);
+int launch_att(K kernel, const AttP& p0, size_t lds, hipStream_t st, int qblock = 64) {
+  {   // hipFuncSetAttribute once per kernel (every instantiation has the same pointer TYPE, so the key is the pointer itself)
+    static std::mutex mu;
+    static std::unordered_map<const void*, size_t> done;
+    std::lock_guard<std::mutex> lk(mu);
+    size_t& have = done[reinterpret_cast<const void*>(kernel)];
+    if (lds > have) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      have = lds;
+    }
+  }
+  AttP p = p0;
+  p.qblocks = (p.t + qblock - 1) / qblock;
+  p.xcd_remap = dts_knob_get(DTS_KNOB_ATT_XCD) != 0;        // DTS_ATT_XCD=0 restores the plain block order (A/B aid)
+  const long long nblk = (long long)p.qblocks * p.n * p.heads;
+  DTS_CHECK_ARG(nblk < (1ll << 31), "dts_attention: grid too large");
+  hipLaunchKernelGGL(kernel, dim3((unsigned)nblk), dim3(256), lds, st, p);
   DTS_CHECK_LAUNCH("dts_attention");
   return DTS_OK;
 }
 
-int g_att_qt = -1;             // DTS_ATT_QT=1|2 forces the query tiles per wave (tuning aid); default: by sequence length
-
 template <typename T>
 int att16(const AttP& p, hipStream_t st) {
-  if (g_att_qt < 0) { const char* e = getenv("DTS_ATT_QT"); g_att_qt = e ? atoi(e) : 0; }
+  const int g_att_qt = dts_knob_get(DTS_KNOB_ATT_QT) > 0 ? dts_knob_get(DTS_KNOB_ATT_QT) : 0;    // DTS_ATT_QT=1|2 forces the query tiles per wave
   const size_t lds = (size_t)2 * 64 * (p.d * 2 + 32);
   switch (p.d) {
     case 64:
@@ -352,8 +388,7 @@ extern "C" int dts_attention(const void* qkv, void* out, int dtype, int n, int t
   DTS_CHECK_ARG(qkv && out, "dts_attention: null pointer");
   DTS_CHECK_ARG(n > 0 && t > 0 && heads > 0, "dts_attention: bad shape");
   DTS_CHECK_ARG(d == 64 || d == 128 || d == 256, "dts_attention: head dim %d unsupported (64/128/256)", d);
-  DTS_CHECK_ARG((long long)n * heads <= 65535, "dts_attention: n*heads too large for grid.y");
-  AttP p{(const char*)qkv, (char*)out, n, t, heads, d, scale * 1.4426950408889634f};
+  AttP p{(const char*)qkv, (char*)out, n, t, heads, d, scale * 1.4426950408889634f, 0, 1};
   hipStream_t st = to_stream(s);
   switch (dtype) {
     case DTS_F32: return att32(p, st);

@@ -724,8 +724,6 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes) {
   return DTS_OK;
 }
 
-int g_tile_override = -1;      // DTS_CONV_TILE=64|128|192 (tuning aid; only honoured when it divides cout)
-
 template <typename T, bool PF>
 int conv_dispatch_tile(const ConvP& p, int tile, hipStream_t st, float* ws, long long ws_bytes) {
   switch (tile) {
@@ -737,10 +735,7 @@ int conv_dispatch_tile(const ConvP& p, int tile, hipStream_t st, float* ws, long
 
 template <typename T>
 int conv_dispatch(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes) {
-  if (g_tile_override < 0) {
-    const char* e = getenv("DTS_CONV_TILE");
-    g_tile_override = e ? atoi(e) : 0;
-  }
+  const int g_tile_override = dts_knob_get(DTS_KNOB_CONV_TILE);     // DTS_CONV_TILE=64|128|192 (tuning aid; only honoured when it divides cout)
   int tile = (p.cout % 192 == 0) ? 192 : (p.cout % 128 == 0 ? 128 : 64);    // measured: tools/conv_bench.py
   if (g_tile_override > 0 && p.cout % g_tile_override == 0) tile = g_tile_override;
   // fragment prefetch pays on the long K loops of the 3x3 layers; f32 (parity mode) keeps the lean order: its 192-cout

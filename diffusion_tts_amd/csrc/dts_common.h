@@ -35,6 +35,21 @@ void dts_set_error(const char* fmt, ...);
 
 static inline hipStream_t to_stream(dts_stream s) { return reinterpret_cast<hipStream_t>(s); }
 
+// ---- tuning knobs (measurement aid: variants are A/B'd interleaved in ONE process, tools/*_bench.py) ------------
+// Slot values: -1 = unset (the launcher's default applies).  Initialised from the environment variable of the same name on
+// first use; dts_set_tuning() overrides at run time.  Knobs only select between kernels / block orders that give the same
+// results.
+enum dts_knob {
+  DTS_KNOB_ATT_XCD = 0,        // DTS_ATT_XCD      0: plain attention block order, 1: XCD-aware (default)
+  DTS_KNOB_ATT_QT = 1,         // DTS_ATT_QT       1|2: query tiles per wave (default: by sequence length)
+  DTS_KNOB_CONV_TILE = 2,      // DTS_CONV_TILE    64|128|192|256: cout tile (only honoured when it divides cout)
+  DTS_KNOB_CONV_SPLITS = 3,    // DTS_CONV_SPLITS  forced split-K factor (0/unset: heuristic)
+  DTS_KNOB_CONV_VARIANT = 4,   // DTS_CONV_VARIANT kernel structure variant (see conv_igemm.hip)
+  DTS_KNOB_GN_FUSE = 5,        // DTS_GN_FUSE      reserved for the GroupNorm fusion A/B
+  DTS_KNOB_COUNT = 16
+};
+int dts_knob_get(int knob);    // defined in elementwise.hip
+
 // ---- element traits -----------------------------------------------------------------------------
 template <typename T> struct ET;
 template <> struct ET<float> {

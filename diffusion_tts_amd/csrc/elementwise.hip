@@ -16,6 +16,31 @@ void dts_set_error(const char* fmt, ...) {
 extern "C" const char* dts_last_error(void) { return g_err; }
 extern "C" int dts_version(void) { return DTS_ABI_VERSION; }
 
+// ---- tuning knobs (dts_common.h) -------------------------------------------------------------------
+static int g_knob[DTS_KNOB_COUNT];
+static bool g_knob_init = false;
+static const char* const g_knob_env[DTS_KNOB_COUNT] = {"DTS_ATT_XCD", "DTS_ATT_QT", "DTS_CONV_TILE", "DTS_CONV_SPLITS",
+                                                       "DTS_CONV_VARIANT", "DTS_GN_FUSE"};
+static void knob_init() {
+  if (g_knob_init) return;
+  for (int i = 0; i < DTS_KNOB_COUNT; ++i) {
+    const char* e = g_knob_env[i] ? getenv(g_knob_env[i]) : nullptr;
+    g_knob[i] = e ? atoi(e) : -1;
+  }
+  g_knob_init = true;
+}
+int dts_knob_get(int knob) {
+  knob_init();
+  return (knob >= 0 && knob < DTS_KNOB_COUNT) ? g_knob[knob] : -1;
+}
+extern "C" int dts_set_tuning(int knob, int value) {
+  knob_init();
+  DTS_CHECK_ARG(knob >= 0 && knob < DTS_KNOB_COUNT, "dts_set_tuning: knob %d", knob);
+  g_knob[knob] = value;
+  return DTS_OK;
+}
+extern "C" int dts_get_tuning(int knob) { return dts_knob_get(knob); }
+
 namespace {
 
 inline int grid1d(long long total, int block = 256, int cap = 256 * 8) {

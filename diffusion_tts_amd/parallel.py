@@ -23,9 +23,49 @@ class CandidateShards:
         self.rank = dist.get_rank(group) if self.enabled else 0
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.collectives = 0
-        # RCCL ("nccl") moves device tensors directly over xGMI; with the gloo backend (CPU tests, or several ranks
-        # sharing one GPU) the few bytes exchanged are staged through the host
-        self.host_staged = self.enabled and dist.get_backend(group) == 'gloo'
+        # RCCL ("nccl") moves device tensors directly over xGMI; gloo moves host tensors.  A tensor on the side the process
+        # group has no backend for is staged through the other side (composite groups such as "cpu:gloo,cuda:nccl" serve both).
+        backend = str(dist.get_backend(group)).lower() if self.enabled else ''
+        self.dev_direct = 'nccl' in backend          # device tensors go out as they are
+        self.host_direct = 'gloo' in backend or not self.enabled
+        self.host_staged = self.enabled and not self.dev_direct    # device payloads take the host route (gloo-only groups)
+
+    def _device(self):
+        return torch.device('cuda', torch.cuda.current_device())
+
+    def require_candidates(self, n_candidates: int, what: str):
+        """Every rank must own at least one candidate: an empty shard would skip the collectives its peers then wait in forever.
+        Raised identically on every rank (the arguments are replicated)."""
+        if self.world > n_candidates:
+            raise ValueError(f'{what}: N={n_candidates} candidates cannot be sharded over {self.world} ranks (need N >= ranks); '
+                             f'run with fewer ranks or shard_candidates=False')
+
+    def broadcast_host(self, t: torch.Tensor, src_rank: int = 0) -> torch.Tensor:
+        """Replicates a HOST tensor from `src_rank` (group rank) in place and returns it."""
+        if self.world == 1:
+            return t
+        src = src_rank if self.group is None else dist.get_global_rank(self.group, src_rank)
+        if self.host_direct:
+            dist.broadcast(t, src=src, group=self.group)
+        else:
+            d = t.to(self._device())
+            dist.broadcast(d, src=src, group=self.group)
+            t.copy_(d.cpu())
+        self.collectives += 1
+        return t
+
+    def replicate_scale_table(self, scale_fn, steps: int, K: int, N: int):
+        """The eps-greedy step-size table (edm/main.py:776) comes from Python's per-process salted `hash()`: under
+        torch.distributed.run every rank would build different candidates and rebuild a different pivot.  Rank 0's table is the
+        single-process one; it is computed there once and broadcast ([steps,K,N] f64, a few KB), and every rank looks it up."""
+        tab = torch.zeros(steps, K, N, dtype=torch.float64)
+        if self.rank == 0 or self.world == 1:
+            for i in range(steps):
+                for k in range(K):
+                    for n in range(N):
+                        tab[i, k, n] = scale_fn(i, k, n)
+        self.broadcast_host(tab, 0)
+        return lambda i, k, n: float(tab[i, k, n])
 
     def span(self, n_candidates: int, rank: int = None) -> Tuple[int, int]:
         """Contiguous, near-even split of [0, N) (the first N % world ranks get one extra)."""
@@ -41,7 +81,10 @@ class CandidateShards:
             return local
         q, rem = divmod(n_candidates, self.world)
         cap = (q + (1 if rem else 0)) * rows_per_candidate
-        dev = torch.device('cpu') if self.host_staged else local.device
+        if local.is_cuda:
+            dev = local.device if self.dev_direct else torch.device('cpu')
+        else:
+            dev = local.device if self.host_direct else self._device()
         send = torch.zeros(cap, dtype=local.dtype, device=dev)
         send[:local.numel()] = local.reshape(-1).to(dev)
         recv = torch.empty(cap * self.world, dtype=local.dtype, device=dev)
@@ -60,10 +103,14 @@ class CandidateShards:
             return tensor
         owner = next(r for r in range(self.world) if self.span(n_candidates, r)[0] <= candidate < self.span(n_candidates, r)[1])
         src = owner if self.group is None else dist.get_global_rank(self.group, owner)
-        if self.host_staged and tensor.is_cuda:
+        if tensor.is_cuda and not self.dev_direct:
             host = tensor.cpu()
             dist.broadcast(host, src=src, group=self.group)
             tensor.copy_(host)
+        elif not tensor.is_cuda and not self.host_direct:
+            d = tensor.to(self._device())
+            dist.broadcast(d, src=src, group=self.group)
+            tensor.copy_(d.cpu())
         else:
             dist.broadcast(tensor, src=src, group=self.group)
         self.collectives += 1
@@ -79,14 +126,6 @@ class CandidateShards:
         name, keys, pos, has_gauss, cached = np.random.get_state()
         t = torch.cat([torch.from_numpy(keys.astype(np.int64)), torch.tensor([pos, has_gauss], dtype=torch.int64)])
         g = torch.tensor([cached], dtype=torch.float64)
-        src = 0 if self.group is None else dist.get_global_rank(self.group, 0)
-        if self.host_staged:
-            dist.broadcast(t, src=src, group=self.group)
-            dist.broadcast(g, src=src, group=self.group)
-        else:
-            dev = torch.device('cuda', torch.cuda.current_device())
-            td, gd = t.to(dev), g.to(dev)
-            dist.broadcast(td, src=src, group=self.group)
-            dist.broadcast(gd, src=src, group=self.group)
-            t, g = td.cpu(), gd.cpu()
+        self.broadcast_host(t, 0)
+        self.broadcast_host(g, 0)
         np.random.set_state((name, t[:-2].numpy().astype(np.uint32), int(t[-2]), int(t[-1]), float(g[0])))

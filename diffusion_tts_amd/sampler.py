@@ -126,6 +126,7 @@ def _rejection(L: _Loop, t_steps, x_next, labels, p, pre):
     """edm/main.py:101-137; rows are b-major (repeat_interleave).  Sharded: rank r carries candidates [lo,hi) of
     every sample through all steps; rewards all-gathered once; the winner's image broadcast from its owner."""
     N, B = p.N, x_next.shape[0]
+    L.shards.require_candidates(N, 'rejection sampling')
     lo, hi = L.shards.span(N)
     nl = hi - lo
     shape1 = tuple(x_next.shape[1:])
@@ -216,6 +217,11 @@ def _eps_greedy(L: _Loop, t_steps, x_next, labels, p, pre):
     lam = p.lambda_param * np.sqrt(3 * 64 * 64)            # scaled by 3*64*64 whatever the resolution (:716)
     N, K, B = p.N, p.K, x_next.shape[0]
     shape = tuple(x_next.shape)
+    L.shards.require_candidates(N, 'eps-greedy / zero-order search')
+    if L.shards.world > 1:
+        # hash()-derived step sizes are salted per process (PYTHONHASHSEED): ranks must share ONE table or their candidates and
+        # rebuilt pivots diverge.  Rank 0's table == the single-process run's.
+        L.scale_fn = L.shards.replicate_scale_table(L.scale_fn, L.num_steps, K, N)
     lo, hi = L.shards.span(N)
     nl = hi - lo
     lab_l = None if labels is None else labels.repeat(nl, 1).contiguous()

@@ -30,9 +30,13 @@ typedef void* dts_stream;
 enum dts_dtype { DTS_F32 = 0, DTS_BF16 = 1, DTS_F16 = 2 };
 enum dts_status { DTS_OK = 0, DTS_ERR_ARG = -1, DTS_ERR_LAUNCH = -2, DTS_ERR_UNSUPPORTED = -3 };
 
-#define DTS_ABI_VERSION 101        /* bumped with every change of a signature or of dts_conv_args (101: ev_start/ev_stop) */
+#define DTS_ABI_VERSION 102        /* bumped with every change of a signature or of dts_conv_args (101: ev_start/ev_stop; 102: tuning knobs) */
 int dts_version(void);            /* == DTS_ABI_VERSION of the build; a binding must refuse any other value */
 const char* dts_last_error(void);
+/* Tuning knobs (measurement aid; a knob only selects between kernels / block orders with identical results).  knob: index of
+ * enum dts_knob in csrc/dts_common.h; value -1 = launcher default.  Used by tools/*_bench.py to A/B variants in one process. */
+int dts_set_tuning(int knob, int value);
+int dts_get_tuning(int knob);
 
 /* ---- layout / packing (weight preparation and test plumbing; not on the per-step path) ------------ */
 /* NCHW f32 -> NHWC dtype, and back. */

@@ -106,3 +106,57 @@ def test_seed_sharding_world2_gloo():
     assert got[0] == [s for b in ref[0::2] for s in b.tolist()] and got[1] == [s for b in ref[1::2] for s in b.tolist()]
     assert parse_int_list('1,2,5-8') == [1, 2, 5, 6, 7, 8]
     assert [b.tolist() for b in rank_batches([3, 4, 5], 64, 0, 1)] == [[3, 4, 5]]
+
+
+def _scale_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import numpy as np
+        from diffusion_tts_amd.hashing import builtin_scale
+        from diffusion_tts_amd.parallel import CandidateShards
+        sh = CandidateShards()
+        own = [builtin_scale(i, k, n) for i in range(2) for k in range(2) for n in range(4)]     # salted per process
+        fn = sh.replicate_scale_table(builtin_scale, 2, 2, 4)
+        shared = [fn(i, k, n) for i in range(2) for k in range(2) for n in range(4)]
+        np.random.seed(1000 + rank)                                       # ranks start with different numpy streams ...
+        sh.sync_numpy_rng()                                               # ... and adopt rank 0's (edm/main.py:593)
+        draws = np.random.randint(0, 1000, size=4).tolist()
+        err = None
+        try:
+            sh.require_candidates(1, 'test')                              # N=1 < 2 ranks: same error on every rank, no hang
+        except ValueError as e:
+            err = str(e)
+        sh.require_candidates(2, 'test')
+        q.put((rank, own, shared, draws, err))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_hash_scale_table_and_numpy_rng_are_replicated_from_rank0():
+    """the default `scale_fn` is Python's per-process salted hash(); ranks launched by torch.distributed.run
+    disagree on it.  The sharded loop must use rank 0's table everywhere (== the single-process run)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = []
+    old = os.environ.get('PYTHONHASHSEED')
+    try:
+        for r in range(2):
+            os.environ['PYTHONHASHSEED'] = str(11 + r)                    # what independent launches give: different salts
+            p = ctx.Process(target=_scale_worker, args=(r, 2, port, q))
+            p.start()
+            procs.append(p)
+    finally:
+        if old is None:
+            os.environ.pop('PYTHONHASHSEED', None)
+        else:
+            os.environ['PYTHONHASHSEED'] = old
+    got = {r[0]: r[1:] for r in (q.get(timeout=120) for _ in procs)}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][0] != got[1][0]                                         # the hazard is real: the salted tables differ
+    assert got[0][1] == got[1][1] == got[0][0]                            # both ranks use rank 0's table
+    assert got[0][2] == got[1][2]                                         # same numpy child picks
+    assert got[0][3] == got[1][3] and 'N=1' in got[0][3]

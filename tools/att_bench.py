@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Per-shape throughput of dts_attention on the ADM-64 / DDPM++ / classifier attention shapes (tuning harness, GPU box only).
+
+Variants (tuning knobs, include/dts.h dts_set_tuning) are timed INTERLEAVED in one process, round by round, on random data
+(cdna_hip_programming.md section 5.4 rules 24/25); prints the median per variant and the algorithmic bytes per launch.
+
+    python tools/att_bench.py --n 64 --variants att_xcd=0 att_xcd=1
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from diffusion_tts_amd import ops, _lib
+
+SHAPES = [  # (name, tokens, heads, head_dim)
+    ('ADM L1 32x32 h6', 1024, 6, 64), ('ADM L2 16x16 h9', 256, 9, 64), ('ADM L3 8x8 h12', 64, 12, 64),
+    ('CLS 32x32 h4', 1024, 4, 64), ('CLS 16x16 h6', 256, 6, 64), ('CLS 8x8 h8', 64, 8, 64), ('DDPM++ 16x16 d256', 256, 1, 256),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--n', type=int, default=64)
+    ap.add_argument('--dtype', default='bf16')
+    ap.add_argument('--rounds', type=int, default=9)
+    ap.add_argument('--variants', nargs='*', default=['att_xcd=0', 'att_xcd=1'])
+    a = ap.parse_args()
+    dt = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[a.dtype]
+    variants = [dict((kv.split('=')[0], int(kv.split('=')[1])) for kv in v.split(',')) for v in a.variants]
+    print('variants:', variants)
+    for name, t, heads, d in SHAPES:
+        c = heads * d
+        qkv = torch.randn(a.n, t, 3 * c, device='cuda').to(dt)
+        fl = 4.0 * a.n * heads * t * t * d
+        alg = a.n * t * 4 * c * qkv.element_size()                     # read q,k,v once, write out once
+        ts = [[] for _ in variants]
+        for _ in range(2):
+            ops.attention(qkv, heads, d ** -0.5)
+        for r in range(a.rounds):
+            for vi, v in enumerate(variants):
+                for k, val in v.items():
+                    _lib.set_tuning(k, val)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda._sleep(200_000)
+                e0.record()
+                for _ in range(4):
+                    ops.attention(qkv, heads, d ** -0.5)
+                e1.record()
+                torch.cuda.synchronize()
+                ts[vi].append(e0.elapsed_time(e1) / 4)
+                for k in v:
+                    _lib.set_tuning(k, -1)
+        row = f'{name:20s} T={t:5d}  alg {alg / 1e6:7.1f} MB '
+        for vi, v in enumerate(variants):
+            ms = sorted(ts[vi])[len(ts[vi]) // 2]
+            row += f' | {a.variants[vi]}: {ms * 1e3:7.1f} us {fl / ms / 1e9:7.1f} TF/s {alg / ms / 1e9:6.2f} TB/s'
+        print(row, flush=True)
+
+
+if __name__ == '__main__':
+    main()
