@@ -1,39 +1,43 @@
 #!/usr/bin/env python3
 """bench.py -- candidate U-Net steps/sec of the noise-trajectory-search hot path on MI355X.
 
-Workload (BASELINE.json configs[2], the configuration the metric is quoted on): EDM ImageNet-64 (ADM, 295.9 M
-parameters, random init + the documented weight rule), epsilon-greedy search, N = 64 candidates, ImageNet scorer
-(65.4 M-parameter classifier, random init), sigma step i = 5 of the 18-step schedule with S_churn = 40.
-One "step" = ONE search iteration over the candidate batch: build the 64 candidate noises (K14), one Heun step =
-two denoiser forwards over the 64 candidates (K1-K9), quantise (K10), score the 64 predicted images (K12), gather
-rewards, pick the survivor and rebuild the pivot.  That is 2*64 = 128 candidate U-Net evaluations ("candidate
-U-Net steps") per GPU per step.  Synthetic inputs (N(0,1) latents and noises) are resident in HBM before the timed
-region; the host-RNG + upload inclusive rate is reported separately in DESIGN.md.
+Default workload `adm64_eps_greedy` (BASELINE.json configs[2], the configuration the metric is quoted on): EDM ImageNet-64
+(ADM, 295.9 M parameters, random init + the documented weight rule), epsilon-greedy search, N = 64 candidates IN TOTAL,
+ImageNet scorer (65.4 M-parameter classifier, random init), sigma step i = 5 of the 18-step schedule with S_churn = 40.
+One "step" = ONE search iteration over the candidate batch: build the candidate noises (K14), one Heun step = two denoiser
+forwards over the candidates (K1-K9), quantise (K10), score the predicted images (K12), gather rewards, pick the survivor and
+rebuild the pivot on every rank.  That is 2*64 = 128 candidate U-Net evaluations ("candidate U-Net steps") per step.
+Synthetic inputs (N(0,1) latents and noises) are resident in HBM before the timed region.
 
-Multi-GPU (`--gpus N`, launched by torch.distributed.run): candidates are sharded across ranks, 64 per GPU (weak
-scaling, default) or 64 in total (`--scaling strong`); one RCCL all-gather of the rewards per step.
+Multi-GPU: `python bench.py --gpus N` STARTS N ranks itself (python -m torch.distributed.run, one process per GPU, RCCL) before
+anything touches the GPU; launched under torch.distributed.run it joins the existing job.  Default `--scaling strong`: the 64
+candidates are sharded over the ranks (8 per GPU at 8 GPUs = BASELINE config 3), one RCCL all-gather of the rewards per step;
+the weak-scaling rate (64 candidates per GPU) is measured in the same run and reported as `weak_value`.
 
-Prints ONE JSON line on rank 0 (see the field list in the task contract), including `roofline` for the dominant
-kernel (the implicit-GEMM conv: algorithmic conv FLOPs / summed launch durations measured with HIP events on the
-launch stream) and `cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample).
+Other workloads (their own metric strings; not the headline): `ddpmpp32_rejection` (configs[1]: DDPM++ CIFAR-32, rejection N=16,
+brightness) and `adm64_mcts` (configs[4]: ADM-64 MCTS, S rollouts per timestep, imagenet scorer; one step = one whole search).
+
+Prints ONE JSON line on rank 0 with, besides the contract fields: `roofline` (dominant kernel = the implicit-GEMM conv:
+algorithmic conv FLOPs / summed launch durations from HIP events attached to the kernel's own dispatch), `cpu_baseline` (the CPU
+oracle on this box's host cores, one iteration over the same 64 candidates), `parity` (GPU f32 / f16 / bf16 rewards and argmax
+against that oracle iteration on the SAME inputs, plus index agreement of the 16-bit modes over 8 more iterations) and
+`e2e_evals_per_s` (config 3 end to end through generate_image_grid, host RNG and uploads included).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
-ADM_GFLOP_PER_EVAL = 219.33
+GFLOP_PER_EVAL = {'adm64': 219.33, 'ddpmpp32': 42.38}             # BASELINE.md section 2 / SURVEY.md 8(d)
 CLS_GFLOP_PER_IMG = 38.16
-
+TRAFFIC_PROFILE = 'profiles/r02_hbm_traffic_pmc.json'             # written by tools/pmc_traffic.py from the rocprofv3 --pmc passes
 
 _T0 = time.perf_counter()
 
@@ -41,6 +45,49 @@ _T0 = time.perf_counter()
 def log(msg):
     if int(os.environ.get('RANK', '0')) == 0:
         print(f'[bench +{time.perf_counter() - _T0:7.1f}s] {msg}', file=sys.stderr, flush=True)
+
+
+def parse(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=None)
+    ap.add_argument('--workload', default='adm64_eps_greedy', choices=['adm64_eps_greedy', 'ddpmpp32_rejection', 'adm64_mcts'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f32'])
+    ap.add_argument('--candidates', type=int, default=None, help='candidates in total (strong, default 64) or per GPU (weak)')
+    ap.add_argument('--scaling', default='strong', choices=['weak', 'strong'])
+    ap.add_argument('--scorer', default='imagenet', choices=['imagenet', 'brightness'])
+    ap.add_argument('--S', type=int, default=256, help='adm64_mcts: rollouts per timestep (BASELINE config 5: 256)')
+    ap.add_argument('--mcts-children', type=int, default=4, help='adm64_mcts: children per node (SamplingParams.N)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-parity', action='store_true')
+    ap.add_argument('--no-e2e', action='store_true')
+    ap.add_argument('--no-weak', action='store_true', help='skip the weak-scaling leg of a multi-rank run')
+    ap.add_argument('--conv-table', action='store_true', help='log the per-shape conv launch table of the instrumented steps')
+    ap.add_argument('--cpu-sample', type=int, default=64, help='candidates in the CPU-baseline / parity iteration')
+    a = ap.parse_args(argv)
+    d_steps, d_warm = {'adm64_eps_greedy': (6, 2), 'ddpmpp32_rejection': (20, 3), 'adm64_mcts': (1, 0)}[a.workload]
+    a.steps = d_steps if a.steps is None else a.steps
+    a.warmup = d_warm if a.warmup is None else a.warmup
+    if a.candidates is None:
+        a.candidates = 16 if a.workload == 'ddpmpp32_rejection' else 64
+    return a
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` outside a distributed job: start N ranks (one process per GPU) as CHILD processes of this one,
+    which has not touched the GPU (no HIP call before this point), relay their output and exit with their status.  Never an
+    exec of a process that initialised the GPU."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f'starting {n} ranks: {" ".join(cmd[1:8])} ...')
+    return subprocess.call(cmd, env=env)
 
 
 class HipEvents:
@@ -79,32 +126,26 @@ class HipEvents:
         self.live = []
 
 
-def parse():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=6)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f32'])
-    ap.add_argument('--candidates', type=int, default=64, help='candidates per GPU (weak) or in total (strong)')
-    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
-    ap.add_argument('--scorer', default='imagenet', choices=['imagenet', 'brightness'])
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--conv-table', action='store_true', help='log the per-shape conv launch table of the instrumented steps')
-    ap.add_argument('--cpu-sample', type=int, default=32, help='candidates in the CPU-baseline sample')
-    return ap.parse_args()
+# ----------------------------------------------------------------------------------------------------------------------
+def sigma_steps():
+    import torch
+    idx = torch.arange(18, dtype=torch.float64)
+    t = (80 ** (1 / 7) + idx / 17 * (0.002 ** (1 / 7) - 80 ** (1 / 7))) ** 7
+    return torch.cat([t, torch.zeros(1, dtype=torch.float64)])
 
 
-def cpu_baseline(sample_n, seed=0):
-    """The oracle (CPU restatement of the reference, fp32 torch-CPU ops) on this box's host cores: one epsilon-greedy
-    iteration over `sample_n` candidates = 2*sample_n denoiser rows + sample_n classifier images."""
+def oracle_iteration(sample_n, seed=0):
+    """The oracle (CPU restatement of the reference, fp32 torch-CPU ops) on this box's host cores: ONE epsilon-greedy iteration
+    (sigma step 5) over `sample_n` candidates = 2*sample_n ADM-64 denoiser rows + sample_n classifier images.  Returns the timing
+    record for `cpu_baseline` and the inputs / rewards the `parity` leg replays on the GPU."""
+    import torch
     from diffusion_tts_amd import init as dinit
     from diffusion_tts_amd.config import adm_imagenet64, ClassifierConfig
     from oracle.edm_nets import NetCfg, EDMPrecondOracle
     from oracle.classifier import ClsCfg
     from oracle import sampler as osamp, scorers as oscore
-    # the GPU box gives one GPU's share of the host (16 cores); asking torch for every core the machine has
-    # oversubscribes the cgroup quota and runs ~100x slower
+    # the GPU box gives one GPU's share of the host (16 cores); asking torch for every core the machine has oversubscribes the
+    # cgroup quota and runs ~100x slower
     cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
     torch.set_num_threads(cores)
     cfg = adm_imagenet64()
@@ -121,207 +162,454 @@ def cpu_baseline(sample_n, seed=0):
     t0 = time.perf_counter()
     _, x0 = ctx.heun_step(x.repeat(sample_n, 1, 1, 1), t_steps[5], t_steps[6], 5, eps, lab)
     sc = scorer(osamp.to_uint8(x0), lab, torch.zeros(sample_n))
-    int(sc.argmax())
+    best = int(sc.argmax())
     dt = time.perf_counter() - t0
-    return {'value': round(2 * sample_n / dt, 3), 'unit': 'candidate U-Net steps/sec', 'cores': torch.get_num_threads(),
-            'kind': 'port', 'seconds': round(dt, 2),
-            'sample': f'1 eps-greedy iteration over {sample_n} candidates of the same workload: {2 * sample_n} ADM-64 '
-                      f'denoiser rows + {sample_n} classifier images, fp32 torch-CPU oracle'}
+    rec = {'value': round(2 * sample_n / dt, 3), 'unit': 'candidate U-Net steps/sec', 'cores': torch.get_num_threads(),
+           'kind': 'port', 'seconds': round(dt, 2),
+           'sample': f'1 eps-greedy iteration over {sample_n} candidates of the same workload: {2 * sample_n} ADM-64 '
+                     f'denoiser rows + {sample_n} classifier images, fp32 torch-CPU oracle'}
+    return rec, dict(x=x, eps=eps, lab=lab, rewards=sc.float(), best=best)
 
 
-def main():
-    a = parse()
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    ndev = max(1, torch.cuda.device_count())
-    dev = torch.device('cuda', (local % ndev) if world > 1 else 0)
-    if world > 1:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(dev)
-        # RCCL over xGMI ("nccl" IS RCCL on ROCm).  DTS_DIST_BACKEND=gloo exists only to rehearse the multi-rank control
-        # flow on a one-GPU box (ranks share the card; collectives staged through the host).
-        backend = os.environ.get('DTS_DIST_BACKEND', 'nccl')
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=dev)
-        else:
-            dist.init_process_group(backend)
-    if a.gpus != world and rank == 0 and world > 1:
-        print(f'warning: --gpus {a.gpus} but WORLD_SIZE {world}', file=sys.stderr)
-    torch.cuda.set_device(dev)
+def conv_roofline(a, run_once, reps, dtype_name, value_per_gpu, gflop_per_eval, extra_caches=()):
+    """Per-launch timing of the dominant kernel over `reps` eager repetitions of `run_once` (HIP events attached to the conv
+    kernel's own dispatch)."""
+    import torch
+    from diffusion_tts_amd import ops
+    rec = []
+    orig = ops.conv2d
+    hev = HipEvents()
 
-    from diffusion_tts_amd import init as dinit, ops
-    from diffusion_tts_amd.config import adm_imagenet64
-    from diffusion_tts_amd.networks import EDMPrecond
-    from diffusion_tts_amd.parallel import CandidateShards
-    from diffusion_tts_amd.sampler import _Loop
-    from diffusion_tts_amd.scorers import ImageNetScorer, BrightnessScorer
+    def timed_conv(x1, w, bias=None, **kw):
+        e0, e1 = hev.pair()
+        out = orig(x1, w, bias, timing_events=(e0, e1), **kw)
+        n_, ho, wo, co = out.shape
+        rec.append((2.0 * n_ * ho * wo * co * w.shape[1] * w.shape[2] * w.shape[3], e0, e1,
+                    (tuple(x1.shape), tuple(w.shape), 'x2' if kw.get('x2') is not None else '', 'up' if kw.get('up') else '',
+                     'res' if kw.get('residual') is not None else '', 'bnc' if kw.get('bias_nc') is not None else '',
+                     'stats' if kw.get('gn_stats') else '')))
+        return out
+    ops.conv2d = timed_conv
+    was = [c.enabled for c in extra_caches]
+    for c in extra_caches:                  # the timed region replays HIP graphs; per-launch events need the eager sequence
+        c.enabled = False                   # (the same kernels with the same arguments, launched one by one)
+    try:
+        for s in range(reps):
+            run_once(s)
+        torch.cuda.synchronize()
+    finally:
+        ops.conv2d = orig
+        for c, w_ in zip(extra_caches, was):
+            c.enabled = w_
+    fl = sum(r[0] for r in rec)
+    ms = sum(hev.elapsed_ms(r[1], r[2]) for r in rec)
+    if a.conv_table:                        # per-shape view of the conv launches inside the network (stderr)
+        agg = {}
+        for r in rec:
+            t = agg.setdefault(r[3], [0, 0.0, 0.0])
+            t[0] += 1; t[1] += r[0]; t[2] += hev.elapsed_ms(r[1], r[2])
+        for k_, (c_, f_, m_) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
+            log(f'conv {str(k_):100s} x{c_:4d}  {m_ / reps:7.3f} ms/step  {f_ / m_ / 1e9:7.1f} TFLOP/s')
+    hev.close()
+    ach = fl / (ms * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[dtype_name]
+    traffic, tsrc = None, None
+    try:        # HBM bytes per launch of the dominant kernel: a STATIC figure from committed rocprofv3 --pmc passes of this very
+        # command (counters cannot be collected from inside the process), valid for the default workload/dtype only
+        with open(os.path.join(ROOT, TRAFFIC_PROFILE)) as f:
+            doc = json.load(f)
+        if a.workload == 'adm64_eps_greedy' and dtype_name == 'bf16' and a.candidates == 64 and a.gpus == 1:
+            traffic = round(doc['dominant']['hbm_bytes_per_launch'])
+            tsrc = f'static, from {TRAFFIC_PROFILE} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; not measured in this run)'
+    except Exception:
+        pass
+    return {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+            'traffic': traffic, 'traffic_source': tsrc, 'kernel': 'conv_igemm_kernel', 'launches': len(rec),
+            'avg_launch_us': round(ms * 1e3 / max(1, len(rec)), 2), 'avg_launch_gflop': round(fl / max(1, len(rec)) / 1e9, 3),
+            'conv_ms_per_step': round(ms / reps, 2),
+            'whole_step_frac': round(value_per_gpu * gflop_per_eval * 1e9 / (peak * 1e12), 4)}
 
-    dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[a.dtype]
-    cfg = adm_imagenet64()
-    sd, _ = dinit.refill_degenerate(dinit.edm_state_dict(cfg, 0), 0)
-    log('weights initialised on host')
-    net = EDMPrecond(cfg, sd, device=dev, dtype=dtype)
-    del sd
-    log('denoiser packed on device')
-    import warnings
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        scorer = ImageNetScorer(device=dev, compute_dtype=dtype, seed=1) if a.scorer == 'imagenet' else BrightnessScorer()
-    shards = CandidateShards()
-    n_total = a.candidates * world if a.scaling == 'weak' else a.candidates
-    lo, hi = shards.span(n_total)
-    nl = hi - lo
 
-    # ---- synthetic state, resident in HBM before timing
-    g = torch.Generator().manual_seed(1234)                       # same stream on every rank
-    L = _Loop(net, dev, 18, 40, 0.05, 50, 1.003, None, shards)
-    step_indices = torch.arange(18, dtype=torch.float64)
-    t_steps = (80 ** (1 / 7) + step_indices / 17 * (0.002 ** (1 / 7) - 80 ** (1 / 7))) ** 7
-    t_steps = torch.cat([t_steps, torch.zeros(1, dtype=torch.float64)])
-    i_step = 5
-    x_cur = (torch.randn(1, 3, 64, 64, generator=g, dtype=torch.float64) * t_steps[i_step]).to(dev)
-    pivot = torch.randn(1, 3, 64, 64, generator=g, dtype=torch.float64).to(dev)
-    labels = torch.eye(1000)[torch.tensor([7])].to(dev)
-    lab_l = labels.repeat(nl, 1).contiguous()
-    total_steps = a.warmup + a.steps
-    noise, modes, scales = [], [], []
-    lam = 0.15 * np.sqrt(3 * 64 * 64)
-    for s in range(min(total_steps, 4)):                          # 4 distinct noise sets, cycled
-        gfull = torch.randn(n_total, 3, 64, 64, generator=g, dtype=torch.float64)
-        noise.append(gfull[lo:hi].to(dev).contiguous())
-        m = (torch.rand(n_total, generator=g) < 0.6).to(torch.int32)
-        sc = (torch.rand(n_total, generator=g) * lam).float()
-        modes.append((m, m[lo:hi].to(dev).contiguous()))
-        scales.append((sc, sc[lo:hi].to(dev).contiguous()))
-    state = {'pivot': pivot}
+# ----------------------------------------------------------------------------------------------------------------------
+class Job:
+    """Process-group plumbing shared by the workloads."""
 
-    def one_step(s):
-        q = s % len(noise)
-        cand = ops.candidate_noise(state['pivot'], noise[q], modes[q][1], scales[q][1])
-        _, x0 = L.step(x_cur, t_steps[i_step], t_steps[i_step + 1], i_step, cand, lab_l, nb=nl)
-        loc = L.score(scorer, x0, lab_l).to(dev, torch.float32)
-        scores = shards.gather_rewards(loc, n_total, 1).cpu()
-        best = int(scores.argmax())
-        if lo <= best < hi:                                       # survivor rebuilt locally; replicated via host noise in the real loop
-            j = best - lo
-            state['pivot'] = ops.candidate_noise(state['pivot'], noise[q][j:j + 1].contiguous(), modes[q][1][j:j + 1].contiguous(),
-                                                 scales[q][1][j:j + 1].contiguous())
+    def __init__(self, a):
+        import torch
+        import torch.distributed as dist
+        self.a, self.torch, self.dist = a, torch, dist
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        self.rank = int(os.environ.get('RANK', '0'))
+        local = int(os.environ.get('LOCAL_RANK', '0'))
+        if a.gpus != self.world:
+            # under torch.distributed.run the job size is WORLD_SIZE; a different --gpus is a launch mistake, not something to
+            # paper over (a silent n_gpus=1 line was what round 1 printed for `--gpus 8`)
+            print(f'bench.py: --gpus {a.gpus} but WORLD_SIZE={self.world}; launch with `python bench.py --gpus N` (it starts the '
+                  f'ranks itself) or with torch.distributed.run --nproc-per-node N bench.py --gpus N', file=sys.stderr)
+            sys.exit(2)
+        ndev = max(1, torch.cuda.device_count())
+        self.dev = torch.device('cuda', (local % ndev) if self.world > 1 else 0)
+        self.backend = None
+        if self.world > 1:
+            os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+            torch.cuda.set_device(self.dev)
+            # RCCL over xGMI ("nccl" IS RCCL on ROCm).  DTS_DIST_BACKEND=gloo exists only to rehearse the multi-rank control flow on
+            # a one-GPU box (ranks share the card; collectives staged through the host).
+            self.backend = os.environ.get('DTS_DIST_BACKEND', 'nccl')
+            if self.backend == 'nccl':
+                dist.init_process_group('nccl', device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend)
+            assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
+        torch.cuda.set_device(self.dev)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier(device_ids=[self.dev.index]) if self.backend == 'nccl' else self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def max_over_ranks(self, dt):
+        if self.world > 1:
+            t = self.torch.tensor([dt], dtype=self.torch.float64, device=self.dev if self.backend == 'nccl' else 'cpu')
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = float(t)
+        return dt
+
+    def timed(self, one_step, steps, warmup):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
+        torch = self.torch
+        for s in range(warmup):
+            one_step(s)
+            torch.cuda.synchronize(self.dev)
+        self.barrier()
+        t0 = time.perf_counter()
+        for s in range(steps):
+            one_step(warmup + s)
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+    def finish(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+class EpsGreedyIteration:
+    """One search iteration of BASELINE config 3 on `n_total` candidates sharded over the job's ranks, inputs resident in HBM."""
+
+    def __init__(self, job, net, scorer, n_total, i_step=5, sets=4, seed=1234):
+        import numpy as np
+        import torch
+        from diffusion_tts_amd import ops
+        from diffusion_tts_amd.parallel import CandidateShards
+        from diffusion_tts_amd.sampler import _Loop
+        self.ops, self.torch = ops, torch
+        self.job, self.net, self.scorer, self.n_total, self.i = job, net, scorer, n_total, i_step
+        dev = job.dev
+        self.shards = CandidateShards()
+        self.shards.require_candidates(n_total, 'bench')
+        self.lo, self.hi = self.shards.span(n_total)
+        self.nl = self.hi - self.lo
+        self.L = _Loop(net, dev, 18, 40, 0.05, 50, 1.003, None, self.shards)
+        self.t_steps = sigma_steps()
+        g = torch.Generator().manual_seed(seed)                       # same stream on every rank
+        self.x_cur = (torch.randn(1, 3, 64, 64, generator=g, dtype=torch.float64) * self.t_steps[i_step]).to(dev)
+        self.pivot0 = torch.randn(1, 3, 64, 64, generator=g, dtype=torch.float64).to(dev)
+        self.pivot = self.pivot0.clone()
+        lab = torch.eye(1000)[torch.tensor([7])].to(dev)
+        self.lab_l = lab.repeat(self.nl, 1).contiguous()
+        lam = 0.15 * np.sqrt(3 * 64 * 64)
+        # the full candidate set is replicated on every rank (as the real loop replicates the host RNG stream): the survivor
+        # is rebuilt everywhere from its index alone
+        self.noise, self.mode, self.scale = [], [], []
+        for _ in range(sets):
+            self.noise.append(torch.randn(n_total, 3, 64, 64, generator=g, dtype=torch.float64).to(dev))
+            self.mode.append((torch.rand(n_total, generator=g) < 0.6).to(torch.int32).to(dev))
+            self.scale.append((torch.rand(n_total, generator=g) * lam).float().to(dev))
+
+    def candidates(self, q, lo, hi):
+        return self.ops.candidate_noise(self.pivot, self.noise[q][lo:hi].contiguous(), self.mode[q][lo:hi].contiguous(),
+                                        self.scale[q][lo:hi].contiguous())
+
+    def __call__(self, s):
+        q = s % len(self.noise)
+        cand = self.candidates(q, self.lo, self.hi)
+        _, x0 = self.L.step(self.x_cur, self.t_steps[self.i], self.t_steps[self.i + 1], self.i, cand, self.lab_l, nb=self.nl)
+        loc = self.L.score(self.scorer, x0, self.lab_l).to(self.job.dev, self.torch.float32)
+        scores = self.shards.gather_rewards(loc, self.n_total, 1).cpu()
+        best = int(scores.argmax())                                   # first max; identical on every rank
+        self.pivot = self.candidates(q, best, best + 1)               # every rank rebuilds the survivor (edm/main.py:848-857)
+        self.last_scores = scores
         return best
 
-    def barrier():
-        if world > 1:
-            dist.barrier(device_ids=[dev.index]) if dist.get_backend() == 'nccl' else dist.barrier()
-        torch.cuda.synchronize(dev)
 
-    # setup, not warm-up: the forwards are captured as HIP graphs on the third call of a shape (graphs.py); two untimed iterations
-    # here keep that one-off capture (~0.5 s) out of the W warm-up steps and the K timed steps whatever W is
-    for s in range(2):
-        one_step(s)
-    torch.cuda.synchronize(dev)
-    log(f'state resident; {nl} candidates on this rank; forwards captured ({net._graphs.captures} graphs); warmup')
-    for s in range(a.warmup):
-        one_step(s)
-        torch.cuda.synchronize(dev)
-        log(f'warmup step {s} done')
+def build_adm(job, dtype, with_scorer=True, scorer_name='imagenet', sd=None):
+    import warnings
+    from diffusion_tts_amd import init as dinit
+    from diffusion_tts_amd.config import adm_imagenet64
+    from diffusion_tts_amd.networks import EDMPrecond
+    from diffusion_tts_amd.scorers import ImageNetScorer, BrightnessScorer
+    cfg = adm_imagenet64()
+    if sd is None:
+        sd, _ = dinit.refill_degenerate(dinit.edm_state_dict(cfg, 0), 0)
+    net = EDMPrecond(cfg, sd, device=job.dev, dtype=dtype)
+    scorer = None
+    if with_scorer:
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            scorer = ImageNetScorer(device=job.dev, compute_dtype=dtype, seed=1) if scorer_name == 'imagenet' else BrightnessScorer()
+    return net, scorer, sd
+
+
+def parity_leg(job, orc, nets):
+    """GPU f32 / f16 / bf16 against the oracle iteration `orc` on the SAME 64 inputs, then index agreement of the 16-bit modes with
+    the f32 mode over 8 more search iterations (K14-built candidates at eight sigma steps with churn)."""
+    import torch
+    from diffusion_tts_amd.sampler import _Loop
+    from diffusion_tts_amd.parallel import CandidateShards
+    dev = job.dev
+    t_steps = sigma_steps()
+    out = {'inputs': f'the cpu_baseline iteration: {orc["eps"].shape[0]} candidates, sigma step 5/18, seed 7'}
+    srt = torch.sort(orc['rewards'], descending=True).values
+    out['oracle_argmax'] = orc['best']
+    out['oracle_top2_gap'] = float(srt[0] - srt[1])
+    n = orc['eps'].shape[0]
+    for name, (net, scorer) in nets.items():
+        L = _Loop(net, dev, 18, 40, 0.05, 50, 1.003, None, CandidateShards(enabled=False))
+        lab = orc['lab'].to(dev)
+        _, x0 = L.step(orc['x'].to(dev), t_steps[5], t_steps[6], 5, orc['eps'].to(dev), lab, nb=n)
+        sc = L.score(scorer, x0, lab).float().cpu()
+        out[name] = {'max_reward_err': float((sc - orc['rewards']).abs().max()), 'argmax': int(sc.argmax()),
+                     'index_equal': bool(int(sc.argmax()) == orc['best'])}
+    steps_i = [2, 3, 5, 7, 9, 11, 13, 14]
+    agree = {name: 0 for name in nets if name != 'f32'}
+    gaps = []
+    for r, i_step in enumerate(steps_i):
+        best = {}
+        for name, (net, scorer) in nets.items():               # same seed => the same state, pivot and candidate set for every dtype
+            it = EpsGreedyIteration(job, net, scorer, n, i_step=i_step, sets=1, seed=4321 + r)
+            best[name] = it(0)
+            if name == 'f32':
+                s = torch.sort(it.last_scores.flatten(), descending=True).values
+                gaps.append(float(s[0] - s[1]))
+        for name in agree:
+            agree[name] += int(best[name] == best['f32'])
+    out['index_agreement'] = {'reference': 'GPU f32 parity mode (checked against the oracle above)', 'iterations': len(steps_i),
+                              'sigma_steps': steps_i, 'f32_top2_gaps': [float(f'{g_:.3e}') for g_ in gaps],
+                              **{name: f'{v}/{len(steps_i)}' for name, v in agree.items()}}
+    return out
+
+
+def e2e_leg(job, net, scorer, dtype):
+    """BASELINE config 3 end to end: generate_image_grid, eps-greedy N=64 K=4, 18 sigma steps, host RNG + uploads included."""
+    import torch
+    from diffusion_tts_amd.sampler import SamplingMethod, generate_image_grid
+    lat = torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(3))
+    lab = torch.eye(1000)[torch.tensor([5])]
+    best = None
+    for rep in range(2):
+        torch.cuda.synchronize(job.dev)
+        t0 = time.perf_counter()
+        res = generate_image_grid(net, None, lat, lab, seed=0, gridw=1, gridh=1, device=job.dev, num_steps=18, S_churn=40,
+                                  S_min=0.05, S_max=50, S_noise=1.003, sampling_method=SamplingMethod.EPS_GREEDY,
+                                  sampling_params=dict(scorer=scorer, N=64, K=4, lambda_param=0.15, eps=0.4),
+                                  compute_dtype=dtype, verbose=False)
+        torch.cuda.synchronize(job.dev)
+        dt = time.perf_counter() - t0
+        rate = res['net_rows'] / dt
+        best = rate if best is None else max(best, rate)
+    return {'e2e_evals_per_s': round(best, 1), 'e2e_rows': res['net_rows'], 'e2e_seconds_per_image': round(res['net_rows'] / best, 3)}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def run_eps_greedy(a, job):
+    import torch
+    dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[a.dtype]
+    world, rank = job.world, job.rank
+    net, scorer, sd = build_adm(job, dtype, scorer_name=a.scorer)
+    log('denoiser + scorer packed on device')
+    n_total = a.candidates * world if a.scaling == 'weak' else a.candidates
+    it = EpsGreedyIteration(job, net, scorer, n_total)
+    # setup, not warm-up: the forwards are captured as HIP graphs on the third call of a shape (graphs.py); untimed iterations here
+    # keep that one-off capture (~0.5 s) out of the W warm-up steps and the K timed steps whatever W is
+    for s in range(3):
+        it(s)
+    torch.cuda.synchronize(job.dev)
+    log(f'state resident; {it.nl} of {n_total} candidates on this rank; forwards captured ({net._graphs.captures} graphs)')
     evals0 = net.evals
-    barrier()
-    t0 = time.perf_counter()
-    for s in range(a.steps):
-        one_step(a.warmup + s)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
-    log(f'timed region: {dt:.3f}s for {a.steps} steps')
+    dt = job.timed(it, a.steps, a.warmup)
     rows_local = net.evals - evals0
-    rows_total = 2 * n_total * a.steps
-    value = rows_total / dt
+    value = 2 * n_total * a.steps / dt
+    log(f'timed region: {dt:.3f}s for {a.steps} steps -> {value:.1f} evals/s')
 
-    # ---- per-kernel timing of the dominant kernel (implicit-GEMM conv) with HIP events on the launch stream
+    weak = None
+    if world > 1 and a.scaling == 'strong' and not a.no_weak:        # weak-scaling rate in the same run (64 candidates PER GPU)
+        itw = EpsGreedyIteration(job, net, scorer, a.candidates * world)
+        for s in range(3):
+            itw(s)
+        dtw = job.timed(itw, a.steps, 1)
+        weak = 2 * a.candidates * world * a.steps / dtw
+        del itw
+        log(f'weak-scaling leg: {weak:.1f} evals/s')
+
     roof = None
-    if not a.no_kernel_timing and rank != 0:
-        for s in range(min(2, a.steps)):           # the steps contain the reward all-gather: every rank must take part
-            one_step(a.warmup + s)
-        torch.cuda.synchronize(dev)
-    if not a.no_kernel_timing and rank == 0:
-        rec = []
-        orig = ops.conv2d
-        hev = HipEvents()
-
-        def timed_conv(x1, w, bias=None, **kw):
-            e0, e1 = hev.pair()
-            out = orig(x1, w, bias, timing_events=(e0, e1), **kw)
-            n_, ho, wo, co = out.shape
-            rec.append((2.0 * n_ * ho * wo * co * w.shape[1] * w.shape[2] * w.shape[3], e0, e1,
-                        (tuple(x1.shape), tuple(w.shape), 'x2' if kw.get('x2') is not None else '', 'up' if kw.get('up') else '',
-                         'res' if kw.get('residual') is not None else '', 'bnc' if kw.get('bias_nc') is not None else '',
-                         'stats' if kw.get('gn_stats') else '')))
-            return out
-        ops.conv2d = timed_conv
+    if not a.no_kernel_timing:
         caches = [net._graphs] + ([scorer.model._graphs] if hasattr(scorer, 'model') else [])
-        was = [c.enabled for c in caches]
-        for c in caches:                      # the timed region replays HIP graphs; per-launch events need the eager sequence
-            c.enabled = False                 # (the same kernels with the same arguments, launched one by one)
-        try:
-            for s in range(min(2, a.steps)):
-                one_step(a.warmup + s)
-            torch.cuda.synchronize(dev)
-        finally:
-            ops.conv2d = orig
-            for c, w_ in zip(caches, was):
-                c.enabled = w_
-        fl = sum(r[0] for r in rec)
-        ms = sum(hev.elapsed_ms(r[1], r[2]) for r in rec)
-        if a.conv_table:                      # per-shape view of the conv launches inside the network (stderr)
-            agg = {}
-            for r in rec:
-                t = agg.setdefault(r[3], [0, 0.0, 0.0])
-                t[0] += 1; t[1] += r[0]; t[2] += hev.elapsed_ms(r[1], r[2])
-            for k_, (c_, f_, m_) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
-                log(f'conv {str(k_):100s} x{c_:4d}  {m_ / min(2, a.steps):7.3f} ms/step  {f_ / m_ / 1e9:7.1f} TFLOP/s')
-        hev.close()
-        ach = fl / (ms * 1e-3) / 1e12
-        peak = PEAK_TFLOPS[a.dtype]
-        traffic, tsrc = None, None
-        try:        # HBM bytes per launch of the dominant kernel from the committed PMC passes (cannot be collected in-process)
-            with open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic_pmc.json')) as f:
-                ks = json.load(f)['kernels']
-                k = next(v for name, v in ks.items() if name.startswith('conv_igemm_kernel<bf16_t, 6, 4, 2, 2, true>'))   # dominant variant
-            if a.dtype == 'bf16' and a.candidates == 64:
-                traffic, tsrc = round(k['hbm_bytes_per_launch']), 'profiles/r01_hbm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)'
-        except Exception:
-            pass
-        roof = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                'traffic': traffic, 'traffic_source': tsrc, 'kernel': 'conv_igemm_kernel', 'launches': len(rec),
-                'avg_launch_us': round(ms * 1e3 / len(rec), 2), 'avg_launch_gflop': round(fl / len(rec) / 1e9, 3),
-                'conv_ms_per_step': round(ms / min(2, a.steps), 2),
-                'whole_step_frac': round((value / world) * ADM_GFLOP_PER_EVAL * 1e9 / (peak * 1e12), 4)}
-    barrier()
+        reps = min(2, a.steps)
+        if rank == 0:
+            roof = conv_roofline(a, lambda s: it(a.warmup + s), reps, a.dtype, value / world, GFLOP_PER_EVAL['adm64'], caches)
+        else:                                   # the steps contain the reward all-gather: every rank must take part
+            for s in range(reps):
+                it(a.warmup + s)
+            torch.cuda.synchronize(job.dev)
+    job.barrier()
 
-    cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        log('kernel timing done; CPU baseline (oracle) running')
-        cpu = cpu_baseline(a.cpu_sample)
-        log('CPU baseline done')
-
+    extra = {}
+    if rank == 0 and world == 1:
+        if not a.no_e2e and a.candidates == 64 and a.scorer == 'imagenet':
+            extra.update(e2e_leg(job, net, scorer, dtype))
+            log(f'end-to-end config 3: {extra["e2e_evals_per_s"]} evals/s')
+        cpu = orc = None
+        if not a.no_cpu_baseline:
+            log('CPU baseline (oracle) running')
+            cpu, orc = oracle_iteration(a.cpu_sample)
+            log('CPU baseline done')
+        extra['cpu_baseline'] = cpu
+        if orc is not None and not a.no_parity and a.scorer == 'imagenet':
+            nets = {a.dtype: (net, scorer)}
+            for name, dt_ in (('f32', torch.float32), ('f16', torch.float16), ('bf16', torch.bfloat16)):
+                if name not in nets:
+                    n_, s_, _ = build_adm(job, dt_, sd=sd)
+                    nets[name] = (n_, s_)
+            extra['parity'] = parity_leg(job, orc, {k: nets[k] for k in ('f32', 'f16', 'bf16')})
+            log('parity leg done')
     if rank == 0:
         out = {
             'metric': 'candidate U-Net steps/sec, EDM ImageNet-64 eps-greedy N=64', 'value': round(value, 2),
             'unit': 'candidate U-Net steps/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-            'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': a.scaling,
+            'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': a.scaling if world > 1 else 'strong',
             'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic (N(0,1) latents/noises, random-init weights + weight rule)',
             'config': {'workload': 'EDM ImageNet-64 (ADM 295.9M) eps-greedy search iteration, imagenet scorer, sigma step 5/18',
-                       'candidates_total': n_total, 'candidates_per_gpu': nl, 'rows_per_step_total': 2 * n_total,
+                       'candidates_total': n_total, 'candidates_per_gpu': it.nl, 'rows_per_step_total': 2 * n_total,
                        'scorer': a.scorer, 'parallelism': f'candidates sharded x{world}, 1 all-gather of rewards per step'},
-            'roofline': roof, 'cpu_baseline': cpu,
-            'scorer_images_per_sec': round(n_total * a.steps / dt, 2), 'rows_local': rows_local,
+            'rccl_ranks': world if (world > 1 and job.backend == 'nccl') else (0 if world > 1 else 1),
+            'dist_backend': job.backend, 'weak_value': None if weak is None else round(weak, 2),
+            'roofline': roof, 'cpu_baseline': extra.pop('cpu_baseline', None), 'parity': extra.pop('parity', None),
+            'scorer_images_per_sec': round(n_total * a.steps / dt, 2), 'rows_local': rows_local, **extra,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+
+
+def run_rejection32(a, job):
+    """BASELINE configs[1]: DDPM++ CIFAR-32, rejection sampling over N=16 trajectories, brightness scorer.  One step = one Heun step
+    of the N trajectories (2*N candidate U-Net evaluations) + the score of the predicted images; sigma step 5, S_churn = 40."""
+    import torch
+    from diffusion_tts_amd import init as dinit, ops
+    from diffusion_tts_amd.config import ddpmpp_cifar10
+    from diffusion_tts_amd.networks import EDMPrecond
+    from diffusion_tts_amd.parallel import CandidateShards
+    from diffusion_tts_amd.sampler import _Loop
+    from diffusion_tts_amd.scorers import BrightnessScorer
+    dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[a.dtype]
+    world, rank, dev = job.world, job.rank, job.dev
+    cfg = ddpmpp_cifar10()
+    sd, _ = dinit.refill_degenerate(dinit.edm_state_dict(cfg, 0), 0)
+    net = EDMPrecond(cfg, sd, device=dev, dtype=dtype)
+    scorer = BrightnessScorer()
+    shards = CandidateShards()
+    n_total = a.candidates * world if a.scaling == 'weak' else a.candidates
+    shards.require_candidates(n_total, 'bench')
+    lo, hi = shards.span(n_total)
+    nl = hi - lo
+    L = _Loop(net, dev, 18, 40, 0.05, 50, 1.003, None, shards)
+    t_steps = sigma_steps()
+    g = torch.Generator().manual_seed(99)
+    x = (torch.randn(n_total, 3, 32, 32, generator=g, dtype=torch.float64) * t_steps[5])[lo:hi].to(dev).contiguous()
+    eps = [torch.randn(n_total, 3, 32, 32, generator=g, dtype=torch.float64)[lo:hi].to(dev).contiguous() for _ in range(4)]
+    lab = torch.eye(10)[torch.tensor([3])].repeat(nl, 1).to(dev).contiguous()
+
+    def one_step(s):
+        xn, _ = L.step(x, t_steps[5], t_steps[6], 5, eps[s % 4], lab, nb=nl)
+        loc = L.score(scorer, xn, lab).to(dev, torch.float32)
+        return int(shards.gather_rewards(loc, n_total, 1).cpu().argmax())
+
+    for s in range(3):
+        one_step(s)
+    torch.cuda.synchronize(dev)
+    dt = job.timed(one_step, a.steps, a.warmup)
+    value = 2 * n_total * a.steps / dt
+    roof = None
+    if not a.no_kernel_timing:
+        if rank == 0:
+            roof = conv_roofline(a, lambda s: one_step(s), min(2, a.steps), a.dtype, value / world, GFLOP_PER_EVAL['ddpmpp32'], [net._graphs])
+        else:
+            for s in range(min(2, a.steps)):
+                one_step(s)
+    job.barrier()
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'candidate U-Net steps/sec, EDM CIFAR-10 32x32 rejection N=16', 'value': round(value, 2),
+            'unit': 'candidate U-Net steps/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': a.scaling if world > 1 else 'strong',
+            'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic (N(0,1) latents/noises, random-init weights + weight rule)',
+            'config': {'workload': 'EDM CIFAR-10 (DDPM++ 55.7M) rejection-sampling Heun step over the N trajectories, brightness scorer, sigma step 5/18',
+                       'candidates_total': n_total, 'candidates_per_gpu': nl, 'rows_per_step_total': 2 * n_total,
+                       'gflop_per_eval': GFLOP_PER_EVAL['ddpmpp32'], 'parallelism': f'trajectories sharded x{world}'},
+            'roofline': roof, 'cpu_baseline': None}), flush=True)
+
+
+def run_mcts(a, job):
+    """BASELINE configs[4]: ADM-64 MCTS, S rollouts per timestep, imagenet scorer.  One step = one whole image search through
+    generate_image_grid (18 sigma steps; node expansions batched, ragged rollouts batched and sharded over the ranks)."""
+    import numpy as np
+    import torch
+    from diffusion_tts_amd.sampler import SamplingMethod, generate_image_grid
+    dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[a.dtype]
+    net, scorer, _ = build_adm(job, dtype, scorer_name=a.scorer)
+    lat = torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(3))
+    lab = torch.eye(1000)[torch.tensor([5])]
+
+    def search(S, seed):
+        np.random.seed(seed)
+        return generate_image_grid(net, None, lat, lab, seed=seed, gridw=1, gridh=1, device=job.dev, num_steps=18, S_churn=40,
+                                   S_min=0.05, S_max=50, S_noise=1.003, sampling_method=SamplingMethod.MCTS,
+                                   sampling_params=dict(scorer=scorer, N=a.mcts_children, S=S), compute_dtype=dtype, verbose=False)
+    search(min(a.S, 16), 0)                     # setup: kernel attributes, graph captures of the common batch sizes
+    rows = [0]
+
+    def one_step(s):
+        rows[0] += search(a.S, 1 + s)['net_rows']
+    for s in range(a.warmup):
+        one_step(s)
+    rows[0] = 0
+    dt = job.timed(one_step, a.steps, 0)
+    rows_total = rows[0]                        # rows of THIS rank; rollouts are sharded, expansions replicated
+    if job.world > 1:
+        t = torch.tensor([rows_total], dtype=torch.float64, device=job.dev if job.backend == 'nccl' else 'cpu')
+        job.dist.all_reduce(t)
+        rows_total = int(t)
+    if job.rank == 0:
+        value = rows_total / dt
+        print(json.dumps({
+            'metric': f'candidate U-Net steps/sec, EDM ImageNet-64 MCTS S={a.S}', 'value': round(value, 2),
+            'unit': 'candidate U-Net steps/sec', 'n_gpus': job.world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': round(dt / a.steps * 1e3, 1), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'dtype': a.dtype, 'data': 'synthetic (N(0,1) latents/noises, random-init weights + weight rule)',
+            'config': {'workload': f'EDM ImageNet-64 (ADM 295.9M) MCTS search of one image: 18 sigma steps, {a.mcts_children} children per node, '
+                                   f'S={a.S} rollouts per timestep, imagenet scorer', 'denoiser_rows_per_search': rows_total // max(1, a.steps),
+                       'parallelism': f'rollouts of each group of 16 sharded x{job.world}'},
+            'roofline': {'bound': 'mfma', 'achieved': round(value / job.world * GFLOP_PER_EVAL['adm64'] / 1e3, 1), 'peak': PEAK_TFLOPS[a.dtype],
+                         'unit': 'TFLOP/s', 'frac': round(value / job.world * GFLOP_PER_EVAL['adm64'] * 1e9 / (PEAK_TFLOPS[a.dtype] * 1e12), 4),
+                         'traffic': None, 'kernel': 'whole search (denoiser FLOPs only)'},
+            'cpu_baseline': None}), flush=True)
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(a.gpus))          # before any GPU / HIP call in this process
+    job = Job(a)
+    {'adm64_eps_greedy': run_eps_greedy, 'ddpmpp32_rejection': run_rejection32, 'adm64_mcts': run_mcts}[a.workload](a, job)
+    job.finish()
 
 
 if __name__ == '__main__':

@@ -22,7 +22,8 @@ class CandidateShards:
         self.enabled = enabled and dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank(group) if self.enabled else 0
         self.world = dist.get_world_size(group) if self.enabled else 1
-        self.collectives = 0
+        self.collectives = 0              # data-path collectives (reward all-gathers, survivor broadcasts)
+        self.setup_collectives = 0        # one-off replication of host state (hash scale table, numpy RNG state)
         # RCCL ("nccl") moves device tensors directly over xGMI; gloo moves host tensors.  A tensor on the side the process
         # group has no backend for is staged through the other side (composite groups such as "cpu:gloo,cuda:nccl" serve both).
         backend = str(dist.get_backend(group)).lower() if self.enabled else ''
@@ -51,7 +52,7 @@ class CandidateShards:
             d = t.to(self._device())
             dist.broadcast(d, src=src, group=self.group)
             t.copy_(d.cpu())
-        self.collectives += 1
+        self.setup_collectives += 1
         return t
 
     def replicate_scale_table(self, scale_fn, steps: int, K: int, N: int):

@@ -7,7 +7,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from helpers import oracle_net, oracle_cls_cfg                       # noqa: E402
+from helpers import oracle_net, oracle_cls_cfg, check_decisions      # noqa: E402
 from diffusion_tts_amd import init as dinit                          # noqa: E402
 from diffusion_tts_amd.config import adm_imagenet64, ddpmpp_cifar10, ClassifierConfig   # noqa: E402
 
@@ -125,11 +125,11 @@ def test_baseline_config2_ddpmpp_rejection_full_trajectories():
     labels = torch.eye(10)[torch.tensor([7])]
     o, h, evals = _full_run(cfg, sd, 'rejection', dict(N=4), latents, labels, seed=0)
     assert evals == 4 * 35 and h['net_rows'] == 4 * 35
-    gap = torch.sort(o['rewards'][0].flatten(), descending=True).values
-    if float(gap[0] - gap[1]) > 4e-5:                                    # decision margin above fp32 noise
-        assert torch.equal(o['selected'][0], h['selected'][0])
-        assert (o['x'] - h['x'].cpu()).abs().max().item() < 1e-3
     assert (torch.cat([r.flatten() for r in o['rewards']]) - torch.cat([r.flatten() for r in h['rewards']])).abs().max().item() < 5e-5
+    # rewards are [B, N] here: decide over the candidate axis
+    same, _ = check_decisions([r.t() for r in o['rewards']], o['selected'], h['selected'], 'config 2 rejection')
+    assert same
+    assert (o['x'] - h['x'].cpu()).abs().max().item() < 1e-3
 
 
 def test_baseline_config3_adm64_eps_greedy_imagenet_scorer_reduced(adm):
@@ -157,13 +157,126 @@ def test_baseline_config3_adm64_eps_greedy_imagenet_scorer_reduced(adm):
                                sampling_method=sm.SamplingMethod.EPS_GREEDY, sampling_params=dict(scorer=scorer, **params),
                                scale_fn=seed0_scale, compute_dtype=torch.float32, verbose=False, **kw)
     assert h['net_rows'] == onet.evals
-    same = True
-    for ro, rh, so, sh in zip(o['rewards'], h['rewards'], o['selected'], h['selected']):
-        assert (ro - rh).abs().max().item() < 5e-5
-        top = torch.sort(ro.flatten(), descending=True).values
-        if same and float(top[0] - top[1]) > 4e-5:
-            assert torch.equal(so, sh)
-        elif not torch.equal(so, sh):
-            same = False                                   # a sub-noise decision went the other way: later states differ legitimately
+    same, _ = check_decisions(o['rewards'], o['selected'], h['selected'], 'config 3 eps-greedy (reduced)')
+    for k_, (ro, rh) in enumerate(zip(o['rewards'], h['rewards'])):
+        if same or k_ == 0:
+            assert (ro - rh).abs().max().item() < 5e-5
     if same:
         assert (o['x'] - h['x'].cpu()).abs().max().item() < 1e-3
+
+
+def _adm_and_scorers(adm, dtype):
+    from diffusion_tts_amd import scorers as S
+    from diffusion_tts_amd.networks import EDMPrecond
+    from oracle import scorers as oscore
+    cfg, sd = adm
+    ccfg = ClassifierConfig()
+    csd, _ = dinit.refill_degenerate(dinit.classifier_state_dict(ccfg, 1), 1)
+    net = EDMPrecond(cfg, sd, device=DEV, dtype=dtype)
+    scorer = S.ImageNetScorer(weights=csd, cfg=ccfg, device=DEV, compute_dtype=dtype)
+    return net, scorer, oracle_net(cfg, sd), oscore.ImageNetOracle(oracle_cls_cfg(ccfg), csd)
+
+
+def test_config3_full_candidate_batch_n64_one_iteration_matches_oracle(adm):
+    """BASELINE.json configs[2] at the HEADLINE SIZE: one eps-greedy search iteration (sigma step 5 of 18, S_churn = 40) over all
+    N = 64 candidates built by the candidate builder (K14: pivot + scale * g/||g|| or a fresh Gaussian), full ADM-64 denoiser and
+    full 64x64 classifier, f32 parity mode against the CPU oracle on the same inputs: candidates to 1e-12, the 64 rewards to 5e-5
+    and the SAME selected index (north_star: selected candidate indices bit-exact).  The 16-bit throughput modes are run on the same
+    inputs and their agreement is printed (bench.py reports it in the driver's JSON line)."""
+    from diffusion_tts_amd import ops
+    from diffusion_tts_amd.parallel import CandidateShards
+    from diffusion_tts_amd.sampler import _Loop
+    from oracle import sampler as osamp
+    N, i = 64, 5
+    net, scorer, onet, oscorer = _adm_and_scorers(adm, torch.float32)
+    t_steps = osamp.sigma_schedule(onet, 18)
+    g = torch.Generator().manual_seed(2024)
+    x_cur = torch.randn(1, 3, 64, 64, generator=g, dtype=torch.float64) * t_steps[i]
+    pivot = torch.randn(1, 3, 64, 64, generator=g, dtype=torch.float64)
+    gs = torch.randn(N, 3, 64, 64, generator=g, dtype=torch.float64)
+    mode = (torch.rand(N, generator=g) < 0.6)
+    scale = (torch.rand(N, generator=g) * (0.15 * np.sqrt(3 * 64 * 64))).float()
+    lab = torch.eye(1000)[torch.tensor([207])].repeat(N, 1)
+    # reference candidate formula (edm/main.py:767-795): u = g/||g||_2, cand = pivot + f32 scale * u, or the fresh Gaussian
+    u = gs / torch.norm(gs, p=2, dim=(1, 2, 3), keepdim=True)
+    cand_o = torch.where(mode.view(N, 1, 1, 1), pivot + scale.view(N, 1, 1, 1) * u, gs)
+    ctx = osamp._Ctx(onet, 18, 40, 0.05, 50, 1.003)
+    _, x0_o = ctx.heun_step(x_cur.repeat(N, 1, 1, 1), t_steps[i], t_steps[i + 1], i, cand_o, lab)
+    rew_o = oscorer(osamp.to_uint8(x0_o), lab, torch.zeros(N)).float()
+    best_o = int(rew_o.argmax())
+    top = torch.sort(rew_o, descending=True).values
+    gap = float(top[0] - top[1])
+
+    def gpu(net_, scorer_):
+        L = _Loop(net_, torch.device(DEV), 18, 40, 0.05, 50, 1.003, None, CandidateShards(enabled=False))
+        cand = ops.candidate_noise(pivot.to(DEV), gs.to(DEV), mode.to(torch.int32).to(DEV), scale.to(DEV))
+        _, x0 = L.step(x_cur.to(DEV), t_steps[i], t_steps[i + 1], i, cand, lab.to(DEV), nb=N)
+        return cand.cpu(), x0.cpu(), L.score(scorer_, x0, lab.to(DEV)).float().cpu()
+    cand_h, x0_h, rew_h = gpu(net, scorer)
+    assert (cand_h - cand_o).abs().max().item() < 1e-12
+    err = (rew_h - rew_o).abs().max().item()
+    print(f'config 3, N=64, f32: max reward err {err:.2e}, oracle top-2 gap {gap:.2e}, argmax {int(rew_h.argmax())} (oracle {best_o}), '
+          f'max |x0 - x0_oracle| {(x0_h - x0_o).abs().max().item():.2e}')
+    assert err < 5e-5
+    assert (x0_h - x0_o).abs().max().item() < 1e-3
+    assert gap > 2 * err, f'top-2 gap {gap:.2e} is not above the observed fp32 error {err:.2e}: pick another seed'
+    assert int(rew_h.argmax()) == best_o
+    del net, scorer
+    for dt in (torch.float16, torch.bfloat16):                      # throughput modes: same inputs; agreement is reported, bounded loosely
+        n16, s16, _, _ = _adm_and_scorers(adm, dt)
+        _, _, r16 = gpu(n16, s16)
+        e16 = (r16 - rew_o).abs().max().item()
+        print(f'config 3, N=64, {str(dt).split(".")[-1]}: max reward err {e16:.2e}, argmax {int(r16.argmax())} (oracle {best_o}), '
+              f'oracle rank of its pick {int((rew_o > rew_o[int(r16.argmax())]).sum())}')
+        assert torch.isfinite(r16).all() and e16 < 0.25
+        del n16, s16
+
+
+def test_config5_mcts_full_size_matches_oracle(adm):
+    """BASELINE.json configs[4] (ADM-64 MCTS with the imagenet scorer) at full network size against the oracle: 4 children per node,
+    S = 16 rollouts per timestep, 3 sigma steps, f32 parity mode: every group's rewards to 5e-5, the same chosen child at every
+    timestep (edm/main.py:684-703), the same number of denoiser rows although the build batches expansions and rollouts."""
+    from diffusion_tts_amd import sampler as sm
+    from diffusion_tts_amd.hashing import seed0_scale
+    from oracle import sampler as osamp
+    net, scorer, onet, oscorer = _adm_and_scorers(adm, torch.float32)
+    g = torch.Generator().manual_seed(6)
+    latents = torch.randn(1, 3, 64, 64, generator=g)
+    labels = torch.eye(1000)[torch.tensor([417])]
+    params = dict(N=4, S=16)
+    kw = dict(seed=1, num_steps=3, S_churn=40, S_min=0.05, S_max=50, S_noise=1.003)
+    np.random.seed(0)
+    o = osamp.search(onet, latents, labels, method='mcts', params=dict(scorer=oscorer, **params), scale_fn=seed0_scale, **kw)
+    np.random.seed(0)
+    h = sm.generate_image_grid(net, None, latents, labels, gridw=1, gridh=1, device=torch.device(DEV),
+                               sampling_method=sm.SamplingMethod.MCTS, sampling_params=dict(scorer=scorer, **params),
+                               scale_fn=seed0_scale, compute_dtype=torch.float32, verbose=False, **kw)
+    assert h['net_rows'] == onet.evals
+    assert len(o['rewards']) == len(h['rewards']) == 3 and len(o['selected']) == len(h['selected']) == 3
+    errs = [float((ro - rh.cpu()).abs().max()) for ro, rh in zip(o['rewards'], h['rewards'])]
+    print(f'config 5 (MCTS N=4 S=16, 3 steps), f32: reward errs {errs}, chosen children {[int(s) for s in h["selected"]]} '
+          f'(oracle {[int(s) for s in o["selected"]]}), rows {h["net_rows"]}')
+    assert max(errs) < 5e-5
+    assert [int(s) for s in o['selected']] == [int(s) for s in h['selected']]
+    assert (o['x'] - h['x'].cpu()).abs().max().item() < 1e-3
+
+
+def test_config5_mcts_s256_bf16_smoke(adm):
+    """The S = 256 budget of BASELINE.json configs[4] in the throughput dtype (6 sigma steps to bound the run): ragged batched
+    rollouts, 16 groups of 16 simulations per timestep; row counts follow from the tree shape, everything finite."""
+    from diffusion_tts_amd import sampler as sm
+    net, scorer, _, _ = _adm_and_scorers(adm, torch.bfloat16)
+    g = torch.Generator().manual_seed(8)
+    latents = torch.randn(1, 3, 64, 64, generator=g)
+    labels = torch.eye(1000)[torch.tensor([3])]
+    np.random.seed(0)
+    ns, S, b = 6, 256, 4
+    h = sm.generate_image_grid(net, None, latents, labels, seed=0, gridw=1, gridh=1, device=torch.device(DEV), num_steps=ns,
+                               S_churn=40, S_min=0.05, S_max=50, S_noise=1.003, sampling_method=sm.SamplingMethod.MCTS,
+                               sampling_params=dict(scorer=scorer, N=b, S=S), compute_dtype=torch.bfloat16, verbose=False)
+    assert len(h['rewards']) == ns * (S // 16) and all(r.numel() == 16 for r in h['rewards'])
+    assert all(torch.isfinite(r).all() for r in h['rewards']) and torch.isfinite(h['x']).all()
+    assert len(h['selected']) == ns and all(0 <= int(s) < b for s in h['selected'])
+    # every simulation pushes at least its rollout's rows (or none at the last step) and at most an expansion + a full rollout
+    assert ns * b <= h['net_rows'] <= ns * (2 * b + S * (2 * b + 2 * ns))
+    print(f'config 5 smoke: S=256, {ns} sigma steps, bf16: {h["net_rows"]} denoiser rows, final score {float(h["final_scores"][0]):.4f}')

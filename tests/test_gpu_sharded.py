@@ -45,24 +45,34 @@ def _run(manifest, golden_path, use_dist):
     return out
 
 
-def _worker(rank, world, port, manifest, golden_path, q):
+def _worker(rank, world, port, manifest, golden_path, q, backend='gloo'):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if backend == 'nccl':                         # RCCL: one GPU per rank, device tensors in the collectives
+        torch.cuda.set_device(rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         q.put((rank, _run(manifest, golden_path, True)))
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_search_equals_single_process(manifest):
+@pytest.mark.parametrize('backend', ['gloo', 'nccl'])
+def test_sharded_search_equals_single_process(manifest, backend):
+    """gloo: two ranks share the test box's one GPU (collectives staged through the host).  nccl: the RCCL path itself -- device
+    all_gather_into_tensor / broadcast / init with device_id -- needs two GPUs and is skipped on a one-GPU box."""
     from conftest import ROOT
+    if backend == 'nccl' and torch.cuda.device_count() < 2:
+        pytest.skip('the RCCL variant needs 2 GPUs')
     gp = os.path.join(ROOT, 'tests', 'golden', 'edm_golden.npz')
     single = _run(manifest, gp, False)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, manifest, gp, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, manifest, gp, q, backend)) for r in range(2)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=600) for _ in procs)
