@@ -204,6 +204,21 @@ __global__ __launch_bounds__(256) void brightness_kernel(const uint8_t* __restri
     rewards[blockIdx.x] = fminf(fmaxf(m, 0.f), 1.f);
   }
 }
+// CLIP reward tail (sd/scorers.py:182-183,205-211): e = x / ||x||_2 for image and text embeddings, reward = sum(e_img * e_txt).
+// One wave per row; the norms and the dot product are accumulated in f32 like the reference's f32 tensors; b has n rows or 1.
+__global__ __launch_bounds__(64) void cosine_rows_kernel(const float* __restrict__ a, const float* __restrict__ b, int b_rows,
+                                                          float* __restrict__ out, int d) {
+  const float* pa = a + (size_t)blockIdx.x * d;
+  const float* pb = b + (size_t)(b_rows == 1 ? 0 : blockIdx.x) * d;
+  float na = 0.f, nb = 0.f;
+  for (int i = threadIdx.x; i < d; i += 64) { na += pa[i] * pa[i]; nb += pb[i] * pb[i]; }
+  na = sqrtf(wave_sum(na));
+  nb = sqrtf(wave_sum(nb));
+  float dot = 0.f;
+  for (int i = threadIdx.x; i < d; i += 64) dot += (pa[i] / na) * (pb[i] / nb);
+  dot = wave_sum(dot);
+  if (threadIdx.x == 0) out[blockIdx.x] = dot;
+}
 __global__ void u8_to_unit_kernel(const uint8_t* __restrict__ img, float* __restrict__ out, long long count) {
   GSL(i, count) out[i] = (float)img[i] / 255.0f;
 }
@@ -480,6 +495,14 @@ extern "C" int dts_brightness(const uint8_t* img, float* rewards, int n, int hw,
   ST;
   hipLaunchKernelGGL(brightness_kernel, dim3(n), dim3(256), 0, st, img, rewards, hw);
   DTS_CHECK_LAUNCH("dts_brightness");
+  return DTS_OK;
+}
+extern "C" int dts_cosine_rows(const float* a, const float* b, int b_rows, float* out, int n, int d, dts_stream s) {
+  DTS_CHECK_ARG(a && b && out && n > 0 && d > 0, "dts_cosine_rows: bad args");
+  DTS_CHECK_ARG(b_rows == 1 || b_rows == n, "dts_cosine_rows: b has %d rows for %d", b_rows, n);
+  ST;
+  hipLaunchKernelGGL(cosine_rows_kernel, dim3(n), dim3(64), 0, st, a, b, b_rows, out, d);
+  DTS_CHECK_LAUNCH("dts_cosine_rows");
   return DTS_OK;
 }
 extern "C" int dts_u8_to_unit_f32(const uint8_t* img, float* out, int64_t count, dts_stream s) {

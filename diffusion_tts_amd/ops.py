@@ -343,6 +343,14 @@ def u8_to_unit_f32(img_u8):
     return out
 
 
+def cosine_rows(a, b):
+    """a [n,d] f32, b [n,d] or [1,d] f32 -> [n] f32: cosine similarity of the L2-normalised rows (CLIP reward tail)."""
+    n, d = a.shape
+    out = torch.empty((n,), dtype=torch.float32, device=a.device)
+    _call('dts_cosine_rows', _ptr(a, 'a', torch.float32), _ptr(b, 'b', torch.float32), b.shape[0], _ptr(out), n, d)
+    return out
+
+
 def attnpool_tokens(x, pos):
     n, h, w, c = x.shape
     out = torch.empty((n, h * w + 1, c), dtype=x.dtype, device=x.device)

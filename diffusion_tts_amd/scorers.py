@@ -6,6 +6,10 @@
                        The reference keeps this scorer on the CPU (main.py:69); here it runs beside the denoiser.
   CompressibilityScorer edm/scorers.py:176-243 -> host PIL JPEG byte length, unchanged: entropy coding is a CPU
                        codec and an opaque callable to the search loop.
+  CLIPScorer           sd/scorers.py:149-213   -> HF CLIP image/text towers (third-party arithmetic, run as PyTorch-ROCm
+                       modules on the GPU) + dts_cosine_rows (HIP) for the normalise-and-dot tail.  The reference fetches
+                       `openai/clip-vit-large-patch14`; there is no network here, so the model / image processor / tokenizer
+                       can be injected (random-init `CLIPModel(CLIPConfig)` for BASELINE config 4).
 """
 import io
 import os
@@ -127,3 +131,105 @@ class CompressibilityScorer(Scorer):
         if isinstance(images, list):
             return torch.tensor([self._score(np.array(im)) for im in images])
         return torch.tensor([self._score(np.array(images))])
+
+
+class ByteTokenizer:
+    """Stand-in for CLIP's BPE tokenizer when its vocabulary files are not on disk (no network): UTF-8 bytes shifted past the
+    special ids, `bos ... eos`, padded with eos to the longest prompt of the call, truncated to `max_length` -- the calling
+    convention `CLIPScorer` uses (sd/scorers.py:194-200: padding=True, truncation=True, max_length=77, return_tensors='pt').
+    Deterministic and fixed for a given prompt, which is all a random-init CLIP needs; NOT CLIP's vocabulary."""
+
+    def __init__(self, vocab_size=49408, bos_token_id=None, eos_token_id=None):
+        self.vocab_size = vocab_size
+        self.bos = vocab_size - 2 if bos_token_id is None else bos_token_id
+        self.eos = vocab_size - 1 if eos_token_id is None else eos_token_id
+
+    def __call__(self, prompts, padding=True, truncation=True, max_length=77, return_tensors='pt'):
+        if isinstance(prompts, str):
+            prompts = [prompts]
+        body = self.vocab_size - 2
+        rows = [[self.bos] + [b % body for b in p.encode('utf-8')][:max_length - 2] + [self.eos] for p in prompts]
+        width = max(len(r) for r in rows)
+        ids = torch.tensor([r + [self.eos] * (width - len(r)) for r in rows], dtype=torch.long)
+        mask = torch.tensor([[1] * len(r) + [0] * (width - len(r)) for r in rows], dtype=torch.long)
+        return _Encoding(input_ids=ids, attention_mask=mask)
+
+
+class _Encoding(dict):
+    def to(self, device):
+        return _Encoding({k: v.to(device) for k, v in self.items()})
+
+
+def _features(out):
+    """`CLIPModel.get_image_features` / `get_text_features` return the projected embedding as a tensor (transformers 4.x, what
+    the reference was written against) or inside `BaseModelOutputWithPooling.pooler_output` (transformers 5.x)."""
+    return out if isinstance(out, torch.Tensor) else out.pooler_output
+
+
+class CLIPScorer(Scorer):
+    """Cosine similarity between the CLIP embeddings of the prompt and of each image (sd/scorers.py:149-213).
+
+    `CLIPScorer()` behaves like the reference's: it loads `model_id` through transformers -- from the local HF cache only,
+    since nothing can be downloaded here, and raises with that message when the files are missing.  For runs without the
+    pretrained files pass `model=` (a `transformers.CLIPModel`, e.g. random-init from a `CLIPConfig`), optionally
+    `image_processor=` (default `CLIPImageProcessor()`: the stock 224 / CLIP-mean-std pipeline, no files needed) and
+    `tokenizer=` (default `ByteTokenizer` sized to the model's vocabulary)."""
+
+    def __init__(self, model_id='openai/clip-vit-large-patch14', dtype=torch.float32, model=None, image_processor=None,
+                 tokenizer=None, processor=None, device='cuda'):
+        super().__init__(dtype)
+        self.device = torch.device(device)
+        if processor is not None:                                     # a full CLIPProcessor, as the reference holds
+            image_processor = image_processor or getattr(processor, 'image_processor', processor)
+            tokenizer = tokenizer or getattr(processor, 'tokenizer', None)
+        if model is None:
+            try:
+                from transformers import CLIPModel, CLIPProcessor
+                model = CLIPModel.from_pretrained(model_id, local_files_only=True)
+                proc = CLIPProcessor.from_pretrained(model_id, local_files_only=True)
+                image_processor, tokenizer = proc.image_processor, proc.tokenizer
+            except Exception as e:
+                raise RuntimeError(f'CLIPScorer: {model_id!r} is not in the local Hugging Face cache and cannot be downloaded here; '
+                                   f'pass model= (a transformers.CLIPModel) [and image_processor=/tokenizer=]') from e
+        if image_processor is None:
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                from transformers import CLIPImageProcessor
+                image_processor = CLIPImageProcessor()
+        if tokenizer is None:
+            tc = model.config.text_config
+            tokenizer = ByteTokenizer(tc.vocab_size, getattr(tc, 'bos_token_id', None), getattr(tc, 'eos_token_id', None))
+            if not (0 <= tokenizer.bos < tc.vocab_size and 0 <= tokenizer.eos < tc.vocab_size):
+                tokenizer = ByteTokenizer(tc.vocab_size)
+        self.clip = model.to(self.device).eval()
+        self.image_processor, self.tokenizer = image_processor, tokenizer
+        self._text_cache = {}
+
+    @torch.no_grad()
+    def __call__(self, images, prompts, timesteps=None):
+        dev = self.device
+        # sd/scorers.py:170-173: float images already in [0,1] are not rescaled, everything else (uint8) is
+        do_rescale = not (isinstance(images, torch.Tensor) and images.dtype == torch.float32 and images.max() <= 1.0)
+        if isinstance(images, list):                                   # the SD loop passes [uint8 tensor [1,3,H,W]] (pipeline...:1114)
+            images = [im[0] if (isinstance(im, torch.Tensor) and im.dim() == 4) else im for im in images]
+            images = [im.cpu() if isinstance(im, torch.Tensor) else im for im in images]
+        elif isinstance(images, torch.Tensor):
+            images = images.cpu()
+        pix = self.image_processor(images=images, return_tensors='pt', do_rescale=do_rescale)['pixel_values']
+        img_emb = _features(self.clip.get_image_features(pixel_values=pix.to(self.dtype).to(dev))).float().contiguous()
+        n = img_emb.shape[0]
+        if prompts is None:
+            return torch.zeros(n, device=dev)                          # :186-188
+        if not isinstance(prompts, list):
+            prompts = [prompts] * n
+        elif len(prompts) == 1 and n > 1:
+            prompts = prompts * n
+        key = tuple(prompts)
+        txt_emb = self._text_cache.get(key)                            # the prompt is fixed over a search: encode it once
+        if txt_emb is None:
+            enc = self.tokenizer(prompts, padding=True, truncation=True, max_length=77, return_tensors='pt').to(dev)
+            txt_emb = _features(self.clip.get_text_features(**enc)).float().contiguous()
+            if len(self._text_cache) < 64:
+                self._text_cache[key] = txt_emb
+        return ops.cosine_rows(img_emb, txt_emb).to(self.dtype)        # :182-183,205-211 (normalise both, row-wise dot)

@@ -30,7 +30,7 @@ typedef void* dts_stream;
 enum dts_dtype { DTS_F32 = 0, DTS_BF16 = 1, DTS_F16 = 2 };
 enum dts_status { DTS_OK = 0, DTS_ERR_ARG = -1, DTS_ERR_LAUNCH = -2, DTS_ERR_UNSUPPORTED = -3 };
 
-#define DTS_ABI_VERSION 102        /* bumped with every change of a signature or of dts_conv_args (101: ev_start/ev_stop; 102: tuning knobs) */
+#define DTS_ABI_VERSION 103        /* bumped with every change of a signature or of dts_conv_args (101: ev_start/ev_stop; 102: tuning knobs; 103: dts_cosine_rows) */
 int dts_version(void);            /* == DTS_ABI_VERSION of the build; a binding must refuse any other value */
 const char* dts_last_error(void);
 /* Tuning knobs (measurement aid; a knob only selects between kernels / block orders with identical results).  knob: index of
@@ -144,6 +144,8 @@ int dts_quantize_u8(const void* x, int is_f32, uint8_t* out, int64_t count, dts_
 /* rewards[n] = clamp(mean_hw(0.2126 R + 0.7152 G + 0.0722 B)/1, 0, 1) on u8/255 images NCHW [n][3][h][w] */
 int dts_brightness(const uint8_t* img, float* rewards, int n, int hw, dts_stream s);
 /* f32 NCHW = u8 / 255.0f (scorers.py:153) */
+/* CLIP reward tail (sd/scorers.py:182-183,205-211): out[i] = <a_i/||a_i||, b_i/||b_i||>, f32; b has n rows or 1 (one prompt). */
+int dts_cosine_rows(const float* a, const float* b, int b_rows, float* out, int n, int d, dts_stream s);
 int dts_u8_to_unit_f32(const uint8_t* img, float* out, int64_t count, dts_stream s);
 
 /* ---- K12 tail: attention pool + softmax-gather (unet.py:61-69; scorers.py:162-172) ---------------- */

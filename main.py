@@ -33,12 +33,12 @@ def get_scorer(backend, scorer_name, device):
     from diffusion_tts_amd import scorers as S
     if scorer_name == 'brightness':
         return S.BrightnessScorer(dtype=torch.float32)
-    if scorer_name == 'compressibility':
-        return S.CompressibilityScorer(dtype=torch.float32)
+    if scorer_name == 'compressibility':                               # sd/scorers.py:79 normalises by 150000 bytes, edm/scorers.py:177 by 3000
+        return S.CompressibilityScorer(dtype=torch.float32, max_size=150000 if backend == 'sd' else 3000)
     if scorer_name == 'imagenet' and backend == 'edm':
         return S.ImageNetScorer(dtype=torch.float32, device=device)
     if scorer_name == 'clip' and backend == 'sd':
-        raise ValueError('the CLIP scorer needs HF CLIP weights + tokenizer files, which are not available offline')
+        return S.CLIPScorer(dtype=torch.float32, device=device)        # local HF cache only; raises with instructions otherwise
     raise ValueError(f"Unknown or invalid scorer '{scorer_name}' for backend '{backend}'")
 
 
