@@ -18,7 +18,13 @@ arithmetic on the host, bit-identical to the reference, then uploaded.
 
 Reference quirks kept: SD MCTS never scores or back-propagates (pipeline...:1201-1313), so every timestep takes the
 FIRST expanded child; its rollouts only consume RNG.  The draws are reproduced; the dead U-Net work is skipped unless
-`mcts_dead_compute=True`.
+`mcts_dead_compute=True`.  `mcts_backprop=True` (off by default: the default stays reference-faithful) runs the search the
+reference's code sets out to do -- UCB1 selection, one expansion per simulation, a stochastic DDIM rollout to the last
+timestep, decode + score, visit/reward back-propagation, best-mean child.
+
+Prompt handling (pipeline...:812-814, 976-992, `encode_prompt` :330-460): with a `text_encoder` / `tokenizer` pair the
+pipeline encodes `prompt` and `negative_prompt` itself exactly as `encode_prompt` does; `prompt_embeds` /
+`negative_prompt_embeds` may be passed instead.  Missing `latents` are drawn like `prepare_latents` (:671-690).
 """
 import copy
 import types
@@ -66,7 +72,7 @@ class DDIMScheduler:
         """(prev_sample, pred_original_sample); variance_noise may hold N candidates ([N, *sample.shape]) -> N prev samples."""
         a_t, a_p, sig = self.coefficients(timestep, eta)
         if variance_noise is None and eta > 0:
-            variance_noise = torch.randn(model_output.shape, dtype=torch.float32).to(sample.device, sample.dtype)
+            variance_noise = torch.randn(model_output.shape, dtype=sample.dtype).to(sample.device)   # randn_tensor(..., dtype=model_output.dtype) on the CPU run (:457-460)
         z = variance_noise
         if z is not None and z.dim() == sample.dim():
             z = z.unsqueeze(0)
@@ -76,15 +82,55 @@ class DDIMScheduler:
         return prev, x0
 
 
+class _MCTSNode:
+    __slots__ = ('latents', 'children', 'parent', 'visits', 'total_reward', 'depth')
+
+    def __init__(self, latents, parent=None):
+        self.latents, self.children, self.parent = latents, [], parent
+        self.visits, self.total_reward = 0, 0.0
+        self.depth = 0 if parent is None else parent.depth + 1
+
+    def ucb(self, c):                              # pipeline...:1185-1197
+        if self.visits == 0:
+            return float('inf')
+        pv = self.parent.visits if self.parent else 1
+        return self.total_reward / self.visits + c * np.sqrt(np.log(pv) / self.visits)
+
+
 class SDSearchPipeline:
-    def __init__(self, unet, vae, scheduler: Optional[DDIMScheduler] = None, device='cuda', mcts_dead_compute=False):
+    def __init__(self, unet, vae, scheduler: Optional[DDIMScheduler] = None, device='cuda', mcts_dead_compute=False,
+                 text_encoder=None, tokenizer=None, mcts_backprop=False):
         self.unet, self.vae = unet, vae
         self.scheduler = scheduler or DDIMScheduler()
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise RuntimeError('SDSearchPipeline (HIP) needs a GPU device')
         self.mcts_dead_compute = mcts_dead_compute
+        self.mcts_backprop = mcts_backprop
+        self.text_encoder, self.tokenizer = text_encoder, tokenizer
         self.unet_rows = 0
+
+    def encode_prompt(self, prompt, negative_prompt=None):
+        """(prompt_embeds, negative_prompt_embeds) as `StableDiffusionPipeline.encode_prompt` computes them for one image per
+        prompt with classifier-free guidance (pipeline...:382-460): prompt padded to the tokenizer's model_max_length, the
+        negative prompt ("" by default) padded to the same length, attention mask only if the text encoder asks for one."""
+        if self.text_encoder is None or self.tokenizer is None:
+            raise ValueError('pass prompt_embeds / negative_prompt_embeds, or build the pipeline with text_encoder= and tokenizer=')
+        tok, te = self.tokenizer, self.text_encoder
+        dev = self.device
+        prompts = [prompt] if isinstance(prompt, str) else list(prompt)
+
+        def run(texts, max_length):
+            enc = tok(texts, padding='max_length', max_length=max_length, truncation=True, return_tensors='pt')
+            mask = enc.attention_mask.to(dev) if getattr(getattr(te, 'config', None), 'use_attention_mask', False) else None
+            return te(enc.input_ids.to(dev), attention_mask=mask)[0]
+        pe = run(prompts, tok.model_max_length)
+        neg = [''] * len(prompts) if negative_prompt is None else ([negative_prompt] * len(prompts) if isinstance(negative_prompt, str) else list(negative_prompt))
+        if len(neg) != len(prompts):
+            raise ValueError(f'negative_prompt has batch size {len(neg)}, prompt {len(prompts)}')
+        ne = run(neg, pe.shape[1])
+        dt = getattr(te, 'dtype', pe.dtype)
+        return pe.to(dt), ne.to(dt)
 
     # ------------------------------------------------------------------------------------------
     def _eps(self, x, t, embeds_u, embeds_c, guidance):
@@ -118,22 +164,83 @@ class SDSearchPipeline:
     def _up(self, t, dtype):
         return t.to(self.device, dtype).contiguous()
 
+    def _mcts_backprop(self, timesteps, latents, eu, ec, g, eta, score_function, prompt, scores, params, randn, dtype):
+        """The tree search the reference's MCTS branch sets out to do but never completes (pipeline...:1201-1313 builds the nodes
+        and runs the rollouts, then drops `pred_x0`: no decode, no score, `visits` / `total_reward` never updated, so `best_child`
+        is always the first child).  Behind `mcts_backprop=True` only.  Differences from the reference code, all required for the
+        statistics to mean anything: a node at depth d is expanded and rolled out from timestep index i+d (the reference uses
+        the root's `t` and `range(i, ...)` for every node); the rollout's final latents are decoded and scored; the reward is
+        added along the path to the root.  Host RNG order: per simulation, the expansion noise (if any), then one variance
+        noise per rollout step."""
+        sch, S, N, c = self.scheduler, params['S'], params['N'], params.get('c', 1.414)
+        nT = len(timesteps)
+        best_reward = None
+        for i in range(nT):
+            root = _MCTSNode(latents)
+            root.visits = 1
+            for _ in range(S):
+                node = root
+                while node.children and all(ch.visits > 0 for ch in node.children) and len(node.children) >= N:
+                    node = max(node.children, key=lambda ch: ch.ucb(c))
+                ti = i + node.depth
+                if ti < nT and len(node.children) < N:                         # expansion
+                    t = timesteps[ti]
+                    child_lat, _ = sch.step(self._eps(node.latents, t, eu, ec, g), t, node.latents, eta,
+                                            variance_noise=self._up(randn(), dtype))
+                    node = _MCTSNode(child_lat, parent=node)
+                    node.parent.children.append(node)
+                tmp = node.latents
+                for j in range(i + node.depth, nT):                            # stochastic DDIM rollout to the last timestep
+                    tj = timesteps[j]
+                    tmp, _ = sch.step(self._eps(tmp, tj, eu, ec, g), tj, tmp, eta, variance_noise=self._up(randn(), dtype))
+                r = self._score(score_function, tmp, prompt, scores)[0]
+                best_reward = r if best_reward is None else max(best_reward, r)
+                while node is not None:                                        # back-propagation
+                    node.visits += 1
+                    node.total_reward += r
+                    node = node.parent
+            kids = [ch for ch in root.children if ch.visits > 0]
+            if kids:
+                latents = max(kids, key=lambda ch: ch.total_reward / ch.visits).latents
+        self._mcts_latents = latents
+        return best_reward
+
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def __call__(self, prompt=None, num_inference_steps=100, guidance_scale=7.5, eta=1.0, latents=None, prompt_embeds=None,
-                 negative_prompt_embeds=None, score_function: Optional[Callable] = None, method='eps_greedy', params=None,
-                 output_type='pt'):
+    def __call__(self, prompt=None, num_inference_steps=100, guidance_scale=7.5, negative_prompt=None, eta=1.0, latents=None,
+                 prompt_embeds=None, negative_prompt_embeds=None, score_function: Optional[Callable] = None, method='eps_greedy',
+                 params=None, output_type='pt', height=None, width=None):
+        """Keyword surface of the reference call (pipeline...:785-817) for the arguments the search path uses:
+        `pipe(prompt=..., num_inference_steps=..., score_function=..., method=..., params=...) -> (output, max_score)`."""
+        if prompt is not None and prompt_embeds is not None:                  # check_inputs (:657-661)
+            raise ValueError(f'Cannot forward both `prompt`: {prompt} and `prompt_embeds`. Please make sure to only forward one of the two.')
         if prompt_embeds is None or negative_prompt_embeds is None:
-            raise ValueError('pass prompt_embeds / negative_prompt_embeds (the text encoder is outside this path)')
+            if prompt is None:
+                raise ValueError('pass `prompt` (with a text_encoder/tokenizer in the pipeline) or prompt_embeds + negative_prompt_embeds')
+            pe, ne = self.encode_prompt(prompt, negative_prompt)
+            prompt_embeds = pe if prompt_embeds is None else prompt_embeds
+            negative_prompt_embeds = ne if negative_prompt_embeds is None else negative_prompt_embeds
+        if isinstance(prompt, list):
+            if len(prompt) != 1:
+                raise ValueError('the search loop runs one prompt per call (as main.py:135 of the reference does)')
+            prompt = prompt[0]
         sch, dev = self.scheduler, self.device
         dtype = getattr(self.unet, 'dtype', torch.float32)
         eu, ec = self._up(negative_prompt_embeds, dtype), self._up(prompt_embeds, dtype)
         timesteps = sch.set_timesteps(num_inference_steps)
+        if latents is None:                                                   # prepare_latents (:671-690) on the reference's CPU run
+            cfgu = self.unet.config
+            vsf = 2 ** (len(getattr(self.vae.config, 'block_out_channels', [0] * 4)) - 1)
+            hh = (height // vsf) if height else cfgu.sample_size
+            ww = (width // vsf) if width else cfgu.sample_size
+            latents = torch.randn((1, cfgu.in_channels, hh, ww), dtype=dtype)
         latents = self._up(latents * sch.init_noise_sigma, dtype)
         shape = tuple(latents.shape)
         scores, g = [], float(guidance_scale)
         self.unet_rows = 0
-        randn = lambda: torch.randn(shape, dtype=torch.float32)               # randn_like(latents) on the reference's CPU run
+        # randn_like(latents) on the reference's CPU run draws in the LATENTS' dtype (fp16 latents -> fp16 normal sampler, a
+        # different stream from f32 draws rounded to fp16); the candidate arithmetic (:1371-1379) runs in that dtype too
+        randn = lambda: torch.randn(shape, dtype=dtype)
         max_score = None
 
         if method == 'beam':
@@ -156,6 +263,9 @@ class SDSearchPipeline:
             for lat_c, v in zip(best, finals):
                 if v > max_score:
                     max_score, latents = v, lat_c
+        elif method == 'mcts' and self.mcts_backprop:
+            max_score = self._mcts_backprop(timesteps, latents, eu, ec, g, eta, score_function, prompt, scores, params, randn, dtype)
+            latents = self._mcts_latents
         elif method == 'mcts':
             for i, t in enumerate(timesteps):
                 children = []

@@ -61,17 +61,13 @@ def main_sd(args):
     tok = CLIPTokenizer.from_pretrained(model_id, subfolder='tokenizer', local_files_only=True)
     te = CLIPTextModel.from_pretrained(model_id, subfolder='text_encoder', torch_dtype=torch.float16, local_files_only=True).to(dev)
 
-    def embed(text):
-        ids = tok(text, padding='max_length', max_length=tok.model_max_length, truncation=True, return_tensors='pt').input_ids.to(dev)
-        return te(ids)[0]
     scorer = get_scorer('sd', args.scorer, dev)
-    pipe = SDSearchPipeline(unet, vae, device=dev)
+    pipe = SDSearchPipeline(unet, vae, device=dev, text_encoder=te, tokenizer=tok)     # encodes the prompt itself (pipeline...:976-992)
     params = {'N': args.N, 'lambda': args.lambda_, 'eps': args.eps, 'K': args.K, 'B': args.B, 'S': args.S}
     best, best_score = None, float('-inf')
     for _ in range(params['N'] if args.method == 'rejection' else 1):          # reference main.py:134
         lat = torch.randn(1, unet.config.in_channels, unet.config.sample_size, unet.config.sample_size)
-        out, score = pipe(prompt=args.prompt, prompt_embeds=embed(args.prompt), negative_prompt_embeds=embed(''), latents=lat,
-                          num_inference_steps=50, score_function=scorer, method='naive' if args.method == 'rejection' else args.method,
+        out, score = pipe(prompt=args.prompt, latents=lat, num_inference_steps=50, score_function=scorer, method='naive' if args.method == 'rejection' else args.method,
                           params=params, output_type='pil')
         score = float(score.item() if torch.is_tensor(score) else score)
         if score > best_score:
