@@ -42,8 +42,39 @@ def build(force=False, verbose=False):
             if verbose and warn.strip():
                 print(warn)
     if jobs or force or not os.path.exists(LIB):
+        check_m0(os.path.join(CSRC, 'conv_igemm.o'))
         run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB, *objs])
     return LIB
+
+
+OBJDUMP = os.environ.get('LLVM_OBJDUMP', '/opt/rocm/lib/llvm/bin/llvm-objdump')
+
+
+def check_m0(obj):
+    """conv_igemm.hip writes M0 (the LDS-DMA destination base) in inline asm and declares it clobbered instead of saving and
+    restoring it around every load; hipcc warns that clobbering a reserved register 'may lead to undefined behaviour'.  It is
+    sound only while NO compiler-generated instruction in those kernels uses M0.  This pins that: in the gfx950 code object every
+    instruction that names m0 must be one of our own `s_mov_b32 m0, s<N>` (the LDS-DMA loads read M0 implicitly).  Returns the
+    number of such writes; raises if anything else touches M0."""
+    import glob
+    import tempfile
+    if not os.path.exists(OBJDUMP):
+        return -1
+    with tempfile.TemporaryDirectory() as tmp:
+        local = os.path.join(tmp, 'conv_igemm.o')
+        with open(obj, 'rb') as f, open(local, 'wb') as g:
+            g.write(f.read())
+        subprocess.run([OBJDUMP, '--offloading', local], capture_output=True, text=True, cwd=tmp)
+        dev = glob.glob(local + '.*gfx950*')
+        if not dev:
+            raise RuntimeError('no gfx950 code object found in ' + obj)
+        dis = subprocess.run([OBJDUMP, '-d', dev[0]], capture_output=True, text=True).stdout
+    uses = [ln.split('//')[0].strip() for ln in dis.splitlines() if 'm0' in ln.split('//')[0]]
+    bad = [u for u in uses if not (u.startswith('s_mov_b32 m0, s') and u.count('m0') == 1)]
+    if bad or not uses:
+        raise RuntimeError(f'conv_igemm code object: {len(bad)} instruction(s) other than our `s_mov_b32 m0, sN` use M0 '
+                           f'(first: {bad[:3]}); the M0-clobber shortcut in glds16() is no longer safe')
+    return len(uses)
 
 
 if __name__ == '__main__':

@@ -28,8 +28,11 @@ static_assert(sizeof(dts_conv_args) == 160, "dts_conv_args layout changed: bump 
 
 namespace {
 
-thread_local bool g_stats_written = false;
-thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;   // optional dispatch-attached timing events (dts_conv_args)
+// per-call launch state that is not a kernel argument (no globals: dts_conv2d may be called from several host threads)
+struct ConvCall {
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // optional dispatch-attached timing events (dts_conv_args)
+  bool stats_written = false;
+};
 
 struct ConvP {
   const char* x1; const char* x2;
@@ -677,8 +680,64 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvP kp)
   }
 }
 
+// split-K second pass that ALSO emits the GroupNorm strip statistics the fused epilogue would have written (per 64-pixel strip and
+// channel: sum and sum of squares of the stored, i.e. rounded, outputs).  Without it every split-K layer followed by a GroupNorm
+// costs two more passes (gn_partial + gn_coef): at the 8-candidates-per-GPU batch of a sharded search those were 2.6 ms of a
+// 15.9 ms iteration.  Block = one strip x 256 channels: thread = 4 channels x 16 pixels, then a fixed-order LDS reduction over the
+// four pixel groups (deterministic, no atomics).  Same arithmetic and order as conv_splitk_reduce_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_splitk_reduce_stats_kernel(const ConvP kp) {
+  __shared__ float red[4][64][8];
+  const int strip = blockIdx.x, cq = threadIdx.x & 63, pg = threadIdx.x >> 6;
+  const int co = (blockIdx.y * 64 + cq) * 4;
+  const bool live = co < kp.cout;
+  const T* res = reinterpret_cast<const T*>(kp.residual);
+  const T* bnc = reinterpret_cast<const T*>(kp.bias_nc);
+  T* out = reinterpret_cast<T*>(kp.out);
+  const int hw = kp.hout * kp.wout;
+  float ss[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kp.bias) bv = *reinterpret_cast<const float4*>(kp.bias + co);
+    const int p0 = strip * 64 + pg * 16;
+    const int ns = p0 / hw;                              // a strip never straddles two samples (hw % 64 == 0)
+    float nb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bnc) Vec4<T>::load(bnc + (size_t)ns * kp.ld_bias_nc + co, nb);
+    for (int i = 0; i < 16; ++i) {
+      const int pp = p0 + i;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int s_ = 0; s_ < kp.splits; ++s_) {
+        const float4 q = *reinterpret_cast<const float4*>(kp.partial + ((size_t)s_ * kp.P + pp) * kp.cout + co);
+        v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+      }
+      v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+      if (bnc) { for (int r = 0; r < 4; ++r) v[r] += nb[r]; }
+      if (res) {
+        float f[4];
+        Vec4<T>::load(res + (size_t)pp * kp.cout + co, f);
+        for (int r = 0; r < 4; ++r) v[r] += f[r];
+      }
+      for (int r = 0; r < 4; ++r) v[r] *= kp.out_scale;
+      const typename Vec4<T>::type pk = Vec4<T>::pack(v);
+      *reinterpret_cast<typename Vec4<T>::type*>(out + (size_t)pp * kp.cout + co) = pk;
+      float f[4];
+      Vec4<T>::unpack(pk, f);                            // moments of the values as stored
+      for (int r = 0; r < 4; ++r) { ss[r] += f[r]; sq[r] += f[r] * f[r]; }
+    }
+  }
+  for (int r = 0; r < 4; ++r) { red[pg][cq][2 * r] = ss[r]; red[pg][cq][2 * r + 1] = sq[r]; }
+  __syncthreads();
+  if (pg == 0 && live) {
+    float o[8];
+    for (int j = 0; j < 8; ++j) o[j] = ((red[0][cq][j] + red[1][cq][j]) + red[2][cq][j]) + red[3][cq][j];
+    float4* d = reinterpret_cast<float4*>(kp.stats + ((size_t)strip * kp.cout + co) * 2);
+    d[0] = make_float4(o[0], o[1], o[2], o[3]);
+    d[1] = make_float4(o[4], o[5], o[6], o[7]);
+  }
+}
+
 template <typename T, int MT, int NT, int WM, int WN, bool PF>
-int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes) {
+int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, ConvCall& call) {
   constexpr int NW = WM * WN;
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
   constexpr int BKE = 8 * ET<T>::EPV;
@@ -701,8 +760,11 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes) {
   splits = (nk + q.ks_per_split - 1) / q.ks_per_split;       // no empty split
   q.splits = splits;
   q.partial = ws;
-  if (splits > 1 || NT != 4) q.stats = nullptr;              // the split-K reduce pass does not produce statistics
-  g_stats_written = q.stats != nullptr;
+  // statistics come from the fused epilogue (whole launches, 64-pixel wave strips) or, under split-K, from the reduce pass
+  float* const stats_req = p.stats;
+  const bool stats_in_reduce = splits > 1 && stats_req != nullptr && (p.hout * p.wout) % 64 == 0 && p.cout % 4 == 0;
+  if (splits > 1 || NT != 4) q.stats = nullptr;
+  call.stats_written = q.stats != nullptr || stats_in_reduce;
   const size_t lds = (size_t)2 * (BM + BN) * 128;
   static bool attr_done = false;
   if (!attr_done) {
@@ -710,12 +772,16 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  if (g_ev_start != nullptr && g_ev_stop != nullptr)
-    hipExtLaunchKernelGGL((conv_igemm_kernel<T, MT, NT, WM, WN, PF>), dim3(nblk, splits), dim3(64 * NW), lds, st, g_ev_start, g_ev_stop, 0, q);
+  if (call.ev_start != nullptr && call.ev_stop != nullptr)
+    hipExtLaunchKernelGGL((conv_igemm_kernel<T, MT, NT, WM, WN, PF>), dim3(nblk, splits), dim3(64 * NW), lds, st, call.ev_start, call.ev_stop, 0, q);
   else
     hipLaunchKernelGGL((conv_igemm_kernel<T, MT, NT, WM, WN, PF>), dim3(nblk, splits), dim3(64 * NW), lds, st, q);
   DTS_CHECK_LAUNCH("dts_conv2d");
-  if (splits > 1) {
+  if (splits > 1 && stats_in_reduce) {
+    q.stats = stats_req;
+    hipLaunchKernelGGL((conv_splitk_reduce_stats_kernel<T>), dim3(p.P / 64, (p.cout + 255) / 256), dim3(256), 0, st, q);
+    DTS_CHECK_LAUNCH("dts_conv2d(split-K reduce + statistics)");
+  } else if (splits > 1) {
     long long g = ((long long)p.P * (p.cout / 4) + 255) / 256;
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL((conv_splitk_reduce_kernel<T>), dim3((int)g), dim3(256), 0, st, q);
@@ -725,28 +791,28 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes) {
 }
 
 template <typename T, bool PF>
-int conv_dispatch_tile(const ConvP& p, int tile, hipStream_t st, float* ws, long long ws_bytes) {
+int conv_dispatch_tile(const ConvP& p, int tile, hipStream_t st, float* ws, long long ws_bytes, ConvCall& call) {
   switch (tile) {
-    case 192: return launch_conv<T, 6, 4, 2, 2, PF>(p, st, ws, ws_bytes);
-    case 128: return launch_conv<T, 4, 4, 2, 2, PF>(p, st, ws, ws_bytes);
-    default: return launch_conv<T, 4, 4, 1, 4, PF>(p, st, ws, ws_bytes);
+    case 192: return launch_conv<T, 6, 4, 2, 2, PF>(p, st, ws, ws_bytes, call);
+    case 128: return launch_conv<T, 4, 4, 2, 2, PF>(p, st, ws, ws_bytes, call);
+    default: return launch_conv<T, 4, 4, 1, 4, PF>(p, st, ws, ws_bytes, call);
   }
 }
 
 template <typename T>
-int conv_dispatch(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes) {
+int conv_dispatch(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, ConvCall& call) {
   const int g_tile_override = dts_knob_get(DTS_KNOB_CONV_TILE);     // DTS_CONV_TILE=64|128|192 (tuning aid; only honoured when it divides cout)
   int tile = (p.cout % 192 == 0) ? 192 : (p.cout % 128 == 0 ? 128 : 64);    // measured: tools/conv_bench.py
   if (g_tile_override > 0 && p.cout % g_tile_override == 0) tile = g_tile_override;
   // fragment prefetch pays on the long K loops of the 3x3 layers; f32 (parity mode) keeps the lean order: its 192-cout
   // tile is already at the 256-VGPR limit
-  if (p.taps == 9 && !std::is_same<T, float>::value) return conv_dispatch_tile<T, true>(p, tile, st, ws, ws_bytes);
-  return conv_dispatch_tile<T, false>(p, tile, st, ws, ws_bytes);
+  if (p.taps == 9 && !std::is_same<T, float>::value) return conv_dispatch_tile<T, true>(p, tile, st, ws, ws_bytes, call);
+  return conv_dispatch_tile<T, false>(p, tile, st, ws, ws_bytes, call);
 }
 
 }  // namespace
 
-extern "C" int dts_conv2d(const dts_conv_args* a, dts_stream s) {
+extern "C" int dts_conv2d(dts_conv_args* a, dts_stream s) {
   DTS_CHECK_ARG(a != nullptr, "dts_conv2d: null args");
   DTS_CHECK_ARG(a->x1 && a->w && a->out, "dts_conv2d: null tensor");
   DTS_CHECK_ARG(a->ksize == 1 || a->ksize == 3, "dts_conv2d: ksize %d", a->ksize);
@@ -757,6 +823,9 @@ extern "C" int dts_conv2d(const dts_conv_args* a, dts_stream s) {
   DTS_CHECK_ARG(a->c1 > 0 && a->c1 % bke == 0 && a->c2 % bke == 0, "dts_conv2d: channels (%d,%d) must be multiples of %d",
                 a->c1, a->c2, bke);
   DTS_CHECK_ARG(a->bias_nc == nullptr || a->ld_bias_nc >= a->cout, "dts_conv2d: ld_bias_nc");
+  // out-of-image rows are read from g_zero16 with a pointer that advances along K like a real row: it must stay inside the page
+  DTS_CHECK_ARG((long long)(a->c1 + a->c2) * (a->dtype == DTS_F32 ? 4 : 2) + 128 <= (long long)sizeof(g_zero16),
+                "dts_conv2d: %d input channels exceed the zero-row page (%d bytes)", a->c1 + a->c2, (int)sizeof(g_zero16));
   ConvP p;
   p.x1 = (const char*)a->x1; p.x2 = (const char*)a->x2; p.w = (const char*)a->w;
   p.bias = a->bias; p.bias_nc = (const char*)a->bias_nc; p.residual = (const char*)a->residual; p.out = (char*)a->out;
@@ -780,9 +849,9 @@ extern "C" int dts_conv2d(const dts_conv_args* a, dts_stream s) {
   DTS_CHECK_ARG(a->workspace == nullptr || ((uintptr_t)a->workspace % 16 == 0 && a->workspace_bytes >= 0), "dts_conv2d: workspace");
   hipStream_t st = to_stream(s);
   int rc = DTS_OK;
-  g_stats_written = false;
-  g_ev_start = (hipEvent_t)a->ev_start; g_ev_stop = (hipEvent_t)a->ev_stop;
-  DTS_DISPATCH_DTYPE(a->dtype, rc = conv_dispatch<T>(p, st, (float*)a->workspace, (long long)a->workspace_bytes));
-  const_cast<dts_conv_args*>(a)->stats_written = g_stats_written ? 1 : 0;
+  ConvCall call;
+  call.ev_start = (hipEvent_t)a->ev_start; call.ev_stop = (hipEvent_t)a->ev_stop;
+  DTS_DISPATCH_DTYPE(a->dtype, rc = conv_dispatch<T>(p, st, (float*)a->workspace, (long long)a->workspace_bytes, call));
+  a->stats_written = call.stats_written ? 1 : 0;
   return rc;
 }

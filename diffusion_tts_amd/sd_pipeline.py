@@ -110,6 +110,7 @@ class SDSearchPipeline:
         self.text_encoder, self.tokenizer = text_encoder, tokenizer
         self.unet_rows = 0
 
+    @torch.no_grad()
     def encode_prompt(self, prompt, negative_prompt=None):
         """(prompt_embeds, negative_prompt_embeds) as `StableDiffusionPipeline.encode_prompt` computes them for one image per
         prompt with classifier-free guidance (pipeline...:382-460): prompt padded to the tokenizer's model_max_length, the

@@ -68,11 +68,12 @@ typedef struct dts_conv_args {
   int64_t workspace_bytes;
   float* stats_out;               /* optional [ceil(P/64)][cout][2] f32: per 64-pixel strip (sum, sumsq) of the stored outputs,
                                      the GroupNorm moments of the NEXT layer fused into this epilogue (needs hout*wout % 64 == 0) */
-  int32_t stats_written;          /* OUT: 1 if stats_out was filled (0 when the launch took the split-K path: fall back to dts_gn_coef) */
+  int32_t stats_written;          /* OUT: 1 if stats_out was filled (0 when the launch took the split-K path: fall back to dts_gn_coef); split-K launches
+                                     emit the statistics from their reduce pass */
   void* ev_start; void* ev_stop;  /* optional hipEvent_t pair attached to the conv kernel's own dispatch (start / end of that kernel, as a
                                      kernel trace sees it; no barrier packets between launches).  Measurement only: bench.py's roofline leg */
 } dts_conv_args;
-int dts_conv2d(const dts_conv_args* a, dts_stream s);
+int dts_conv2d(dts_conv_args* a, dts_stream s);      /* writes a->stats_written; no state is kept between calls (thread-safe) */
 
 /* first / last convolutions of the U-Nets (3 image channels; direct, not MFMA) */
 /* x f32 NCHW [n][3][h][w] -> out NHWC [n][h][w][cout]; w f32 OIHW [cout][3][3][3] */

@@ -36,3 +36,15 @@ def test_product_never_imports_the_oracle():
         p = os.path.join(ROOT, f)
         if os.path.exists(p):
             assert not re.search(r'^\s*(from|import)\s+oracle\b', open(p).read(), flags=re.M)
+
+
+def test_only_our_own_writes_touch_m0_in_the_conv_kernels():
+    """VERDICT r1 hygiene: the conv kernels clobber the reserved M0 register in inline asm; that is sound only while hipcc itself
+    never uses M0 there.  The build checks the disassembly; here it is a test."""
+    import os
+    from diffusion_tts_amd import build
+    obj = os.path.join(build.CSRC, 'conv_igemm.o')
+    if not os.path.exists(obj) or not os.path.exists(build.OBJDUMP):
+        import pytest
+        pytest.skip('object file / llvm-objdump not present')
+    assert build.check_m0(obj) > 100

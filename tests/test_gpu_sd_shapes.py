@@ -90,7 +90,7 @@ def test_fp16_search_at_sd_shapes_matches_reference(sg, clip_scorer, method):
     assert out.images.shape == (1, 3, 512, 512) and out.images.dtype == torch.float16
     dec, safe = meta['decisions'], meta['safe_decisions']
     ncmp = len(out.scores) if safe == len(dec) else dec[safe]['after_calls']
-    tol = 3e-4 if meta['scorer'] == 'brightness' else 2e-4
+    tol = 3e-4 if meta['scorer'] == 'brightness' else 4e-4        # = the generator's decision margins (fp16 CPU vs fp16 GPU convolutions)
     err = np.abs(np.array(out.scores[:ncmp]) - g[f'{method}_scores'][:ncmp]).max()
     print(f'{method} fp16 @ SD shapes: {ncmp}/{len(out.scores)} scores compared ({safe}/{len(dec)} safe decisions), max err {err:.2e}')
     assert err < tol, err
