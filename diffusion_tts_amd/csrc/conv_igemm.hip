@@ -172,7 +172,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 // the generic epilogue below executes ~1.5k instructions per wave (a predicated branch per access, a 64-bit address per
 // vector), which in-kernel stamps put at 9k cycles per block -- as long as 4 K steps -- before the first byte is stored.
 // Arithmetic and its order are the generic path's: ((acc + bias) + bias_nc + residual) * out_scale, rounded once.
-template <typename T, int MT, int NT, int BM, int BN, bool RES, bool BNC, bool STATS>
+template <typename T, int MT, int NT, int BM, int BN, bool RES, bool BNC, bool STATS, int NTHR>
 __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&acc)[MT][NT], int cm0, int pn0, int wm, int wn, int lrow,
                                                    int lq, char* smem_ring, bool bias_in_acc, int stage_off, int early_u0,
                                                    int early_u1) {
@@ -181,8 +181,8 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
   // Staged tile in the idle LDS ring: pixel-major rows of BM*2 bytes, dense (LDS-DMA writes 1 KiB contiguous per
   // wave-instruction, so no padding is possible); the 16-byte chunk c of row r sits at chunk slot c ^ (r & 7), which keeps
   // the accumulator-layout 8-byte accesses (16 rows per lane group) at 2-way bank conflicts instead of 8-way.
-  constexpr int ROWB = BM * 2, CPR = BM / 8, DR = 256 / CPR, DC = 256 - DR * CPR, ITERS = BN * CPR / 256;
-  static_assert(BN * CPR % 256 == 0 && CPR % 8 == 0, "staged tile trips / swizzle groups");
+  constexpr int ROWB = BM * 2, CPR = BM / 8, DR = NTHR / CPR, DC = NTHR - DR * CPR, ITERS = BN * CPR / NTHR;
+  static_assert(BN * CPR % NTHR == 0 && CPR % 8 == 0, "staged tile trips / swizzle groups");
   const int p_cout = kp.cout;
   const int prow0 = wn * 16 * NT + lrow;                 // tile-local pixel of nt = 0; (row & 7) == (lrow & 7) for every nt
   const int col0 = wm * 16 * MT + lq * 4;                // tile-local cout of mt = 0
@@ -195,8 +195,8 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
     // already issued during the last K step into the ring buffer that step did not read (and are complete: that step's
     // vmcnt(0) + barrier covered them); only the rest is fetched here.
     const uint32_t stage = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    issue_residual_pieces<BM, 256>(kp, cm0, pn0, stage, tid, 0, early_u0);
-    issue_residual_pieces<BM, 256>(kp, cm0, pn0, stage, tid, early_u1, ITERS);
+    issue_residual_pieces<BM, NTHR>(kp, cm0, pn0, stage, tid, 0, early_u0);
+    issue_residual_pieces<BM, NTHR>(kp, cm0, pn0, stage, tid, early_u1, ITERS);
   }
   float4 bv[MT];
 #pragma unroll
@@ -283,7 +283,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
     }
   }
   __syncthreads();
-  // copy-out: 16 bytes per lane, whole rows; (row, chunk slot) advance incrementally (256 threads = DR rows + DC chunks)
+  // copy-out: 16 bytes per lane, whole rows; (row, chunk slot) advance incrementally (NTHR threads = DR rows + DC chunks)
   int row = tid / CPR, c = tid - row * CPR;
   char* outb = kp.out + ((size_t)pn0 * p_cout + cm0) * 2;
   typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
@@ -297,7 +297,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
 }
 
 // ---- epilogue of one (cout tile, pixel tile[, K split]): lane holds couts co..co+3 of pixel pp for each (mt, nt)
-template <typename T, int MT, int NT, int BM, int BN>
+template <typename T, int MT, int NT, int BM, int BN, int NTHR = 256>
 __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT][NT], int cm0, int pn0, int split, int wm, int wn,
                                               int lrow, int lq, char* smem, bool bias_in_acc, int stage_off, int early_u0, int early_u1) {
   const int p_P = kp.P, p_cout = kp.cout, p_hout = kp.hout, p_wout = kp.wout;
@@ -320,7 +320,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
   if constexpr (sizeof(T) == 2) {
     if (pn0 + BN <= p_P) {                             // block-uniform
       const bool r_ = kp.residual != nullptr, b_ = kp.bias_nc != nullptr, s_ = NT == 4 && kp.stats != nullptr;
-#define DTS_EPI(R_, B_, S_) conv_epilogue_fast<T, MT, NT, BM, BN, R_, B_, S_>(kp, acc, cm0, pn0, wm, wn, lrow, lq, smem, bias_in_acc, stage_off, early_u0, early_u1)
+#define DTS_EPI(R_, B_, S_) conv_epilogue_fast<T, MT, NT, BM, BN, R_, B_, S_, NTHR>(kp, acc, cm0, pn0, wm, wn, lrow, lq, smem, bias_in_acc, stage_off, early_u0, early_u1)
       if (r_) { if (b_) { if (s_) DTS_EPI(true, true, true); else DTS_EPI(true, true, false); }
                 else    { if (s_) DTS_EPI(true, false, true); else DTS_EPI(true, false, false); } }
       else    { if (b_) { if (s_) DTS_EPI(false, true, true); else DTS_EPI(false, true, false); }
@@ -365,7 +365,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
   // stores 16 contiguous bytes and a wave-instruction covers 1 KiB of whole output rows.
   constexpr bool VIA_LDS = sizeof(T) == 2;
   constexpr int ROWP = BM * 2 + 16;                    // LDS row pitch of the staged tile (pixel-major), bytes
-  static_assert(!VIA_LDS || BN * ROWP <= 2 * (BM + BN) * 128, "staged tile must fit the ring");
+  static_assert(!VIA_LDS || BN * ROWP <= (NTHR == 256 ? 2 * (BM + BN) * 128 : (3 * BM + 2 * BN) * 128), "staged tile must fit the ring");
   const bool want_stats = NT == 4 && kp.stats != nullptr;
   float* sp = want_stats ? kp.stats + ((size_t)((pn0 + wn * 64) >> 6) * p_cout) * 2 : nullptr;
 #pragma unroll
@@ -431,7 +431,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
     char* outb = kp.out + ((size_t)pn0 * p_cout + cm0) * 2;
     const int rows = min(BN, p_P - pn0);
 #pragma unroll 4
-    for (int t = threadIdx.x; t < rows * CPR; t += 256) {
+    for (int t = threadIdx.x; t < rows * CPR; t += NTHR) {
       const int row = t / CPR, c = t - row * CPR;
       typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
       const u32x4_nt v_ = *reinterpret_cast<const u32x4_nt*>(smem + row * ROWP + c * 16);
@@ -646,6 +646,189 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
 #undef ISSUE_TILE
 #undef ADVANCE_K
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Ping-pong variant (16-bit types, cout % 192 == 0): ONE 8-wave block per CU on a 192 x 256 (couts x pixels) tile.
+//
+// Why: in conv_igemm_kernel every wave runs [fragment reads -> 10 LDS-DMA issues -> 48 MFMAs -> vmcnt(0) + barrier] as one serial
+// chain of ~2.1k cycles per K step, and the two co-resident blocks of a CU move in lockstep (profiles/r01_conv_variants.txt), so the
+// matrix pipe idles while both waves of a SIMD read and issue loads (73 % MFMA-busy inside the K loop).  Here the two waves of a SIMD
+// are put in ANTI-PHASE by construction: waves 0-3 (group 0) and waves 4-7 (group 1; wave w and w+4 share a SIMD) alternate between a
+// LOAD segment (fragment reads of K tile t, LDS-DMA issue for later tiles) and a COMPUTE segment (the 48 MFMAs of tile t), group 1 one
+// segment behind group 0, with one workgroup barrier per segment: while one wave of a SIMD issues MFMAs its partner reads LDS and
+// issues DMA (MI355X_MICROARCH.md, "Two waves per SIMD": matrix beside memory is the complementary pairing).  The tile is twice as
+// wide in pixels, so a K step moves 7 LDS-DMA pieces per wave instead of 10 (the weight rows are shared by 256 pixels).
+//
+// Work split: wave = (group g, index i): couts wm*96.. (wm = i & 1), pixels wn*64.. (wn = 2g + (i >> 1)).  Group g therefore reads
+// only pixel half g of the activation tile -> the B halves are private to a group (2 stages each, filled by that group one tile
+// ahead); the weight tile A is read by both groups (3 stages, each group fills its 96 rows two tiles ahead).
+//   LDS: A 3 x 24 KB | B 2 stages x 2 halves x 16 KB = 136 KB.
+// Ordering (segments numbered s; group 0: LOAD(t) = 2t, COMPUTE(t) = 2t+1; group 1 one later):
+//   * a wave's LDS reads are complete (lgkmcnt(0)) before the barrier that ends its LOAD segment;
+//   * a wave's LDS-DMA is complete (vmcnt(0)) before the barrier that ends the NEXT segment (its COMPUTE);
+//   * B_g(t+1) is issued in LOAD(t) into the stage last read in LOAD(t-1) by the same group, read in LOAD(t+1);
+//   * A(t+2) is issued in LOAD(t) (segments 2t, 2t+1) into the stage of A(t-1), last read in segment 2t-1; first read in 2t+4.
+// Accumulation order over K is that of conv_igemm_kernel (tap-major, 64 channels per step, two 32-deep MFMAs): bit-identical outputs.
+template <typename T>
+__global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
+  constexpr int MT = 6, NT = 4, BM = 192, BN = 256, NTHR = 512;
+  constexpr int BKE = 64, ES = 2;
+  constexpr int A_STAGE = BM * 128, B_HALF = 128 * 128, B_OFF = 3 * A_STAGE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const char* const p_x1 = kp.x1; const char* const p_x2 = kp.x2; const char* const p_w = kp.w;
+  const int p_c1 = kp.c1, p_c2 = kp.c2, p_cin = kp.cin, p_win = kp.win, p_hout = kp.hout, p_wout = kp.wout;
+  const int p_taps = kp.taps, p_up = kp.up, p_P = kp.P, p_n_ct = kp.n_ct, p_n_pt = kp.n_pt;
+
+  const int nblk = p_n_ct * p_n_pt;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, j = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int ct = bid % p_n_ct, pt = bid / p_n_ct;
+  const int cm0 = ct * BM, pn0 = pt * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = w >> 2, wi = w & 3;
+  const int wm = wi & 1, wn = 2 * grp + (wi >> 1);
+  const int chunk = lane & 7, r0 = lane >> 3;
+  const int lrow = lane & 15, lq = lane >> 4;
+
+  const int K = p_taps * p_cin;
+  const int steps_per_tap = p_cin / BKE;
+  const int nk_all = p_taps * steps_per_tap;
+  const int ks_begin = blockIdx.y * kp.ks_per_split;
+  const int ks_end = min(nk_all, ks_begin + kp.ks_per_split);
+  const int nk = ks_end - ks_begin;
+
+  const int schunk = (chunk ^ (r0 & 7)) * 16;
+  const char* zsrc = reinterpret_cast<const char*>(g_zero16);
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+  // ---- this lane's rows: A share = rows grp*96 + 8*(wi + 4j) + r0 (j < 3), B share = rows 8*(wi + 4j) + r0 of half grp (j < 4)
+  const char* arow[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+    arow[j] = p_w + ((size_t)(cm0 + grp * 96 + 8 * (wi + 4 * j) + r0) * K + (size_t)ks_begin * BKE) * ES + schunk;
+  const uint32_t a_dst = lds_base + (grp * 96 + 8 * wi) * 128;                   // + j*32*128 + stage*A_STAGE
+  const uint32_t b_dst = lds_base + B_OFF + grp * B_HALF + (8 * wi) * 128;       // + j*32*128 + stage*2*B_HALF
+
+  int pix_n[4], pix_hw[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int pp = pn0 + grp * 128 + 8 * (wi + 4 * j) + r0;
+    if (pp < p_P) {
+      int n, ho, wo;
+      if (kp.hw_shift >= 0) {
+        n = pp >> kp.hw_shift;
+        const int rem = pp & ((1 << kp.hw_shift) - 1);
+        ho = rem >> kp.w_shift; wo = rem & ((1 << kp.w_shift) - 1);
+      } else {
+        const int hw = p_hout * p_wout;
+        n = pp / hw;
+        const int rem = pp - n * hw;
+        ho = rem / p_wout; wo = rem - ho * p_wout;
+      }
+      pix_n[j] = n * kp.hin * p_win;
+      pix_hw[j] = (ho << 16) | wo;
+    } else {
+      pix_n[j] = -1;
+      pix_hw[j] = 0;
+    }
+  }
+  const char* brow[4];
+  int tap = ks_begin / steps_per_tap, ci0 = (ks_begin - tap * steps_per_tap) * BKE;      // K position of the NEXT B tile to issue
+
+#define PP_SET_ROWS(tap_, ci0_)                                                                               \
+  {                                                                                                           \
+    const int dh_ = (p_taps == 9) ? (tap_) / 3 - 1 : 0, dw_ = (p_taps == 9) ? (tap_) % 3 - 1 : 0;             \
+    const char* xb; int cs, cofs;                                                                             \
+    if ((ci0_) < p_c1) { xb = p_x1; cs = p_c1; cofs = (ci0_); } else { xb = p_x2; cs = p_c2; cofs = (ci0_) - p_c1; } \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                           \
+      const int hu = (pix_hw[j] >> 16) + dh_, wu = (pix_hw[j] & 0xffff) + dw_;                                \
+      const bool ok = pix_n[j] >= 0 && (unsigned)hu < (unsigned)p_hout && (unsigned)wu < (unsigned)p_wout;    \
+      const int hs = p_up ? (hu >> 1) : hu, ws = p_up ? (wu >> 1) : wu;                                       \
+      brow[j] = ok ? xb + ((size_t)(pix_n[j] + hs * p_win + ws) * cs + cofs) * ES + schunk : zsrc;            \
+    }                                                                                                         \
+  }
+#define PP_ISSUE_B(stage_)                                                                                    \
+  {                                                                                                           \
+    const uint32_t d_ = b_dst + (stage_) * (2 * B_HALF);                                                      \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) glds16(brow[j], d_ + j * (32 * 128));                       \
+    ci0 += BKE;                                                                                               \
+    if (ci0 == p_cin) { ci0 = 0; ++tap; if (tap < p_taps) PP_SET_ROWS(tap, 0); }                              \
+    else if (ci0 == p_c1) { PP_SET_ROWS(tap, ci0); }                                                          \
+    else { _Pragma("unroll") for (int j = 0; j < 4; ++j) brow[j] += BKE * ES; }                               \
+  }
+#define PP_ISSUE_A(t_)                                                                                        \
+  {                                                                                                           \
+    const uint32_t d_ = a_dst + ((t_) % 3) * A_STAGE;                                                         \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) glds16(arow[j] + (size_t)(t_) * (BKE * ES), d_ + j * (32 * 128)); \
+  }
+
+  const bool bias_in_acc = kp.splits == 1 && kp.bias != nullptr;
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias_in_acc) b0 = *reinterpret_cast<const float4*>(kp.bias + cm0 + wm * 96 + i * 16 + lq * 4);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{b0.x, b0.y, b0.z, b0.w};
+  }
+
+  // ---- prologue: A(0), A(1), B_g(0)
+  PP_ISSUE_A(0);
+  if (nk > 1) PP_ISSUE_A(1);
+  PP_SET_ROWS(tap, ci0);
+  PP_ISSUE_B(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");
+  if (grp == 1) asm volatile("s_barrier" ::: "memory");          // the stagger: group 1 runs one segment behind group 0
+
+  for (int t = 0; t < nk; ++t) {
+    // ---------------- LOAD(t): fragments of tile t -> registers; DMA for B_g(t+1) and this group's rows of A(t+2)
+    const char* sa = smem + (t % 3) * A_STAGE + (wm * 96) * 128;
+    const char* sb = smem + B_OFF + ((t & 1) * 2 + grp) * B_HALF + ((wn & 1) * 64) * 128;
+    uint4 fa[MT], fb[NT], ga[MT], gb[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) fb[i] = *reinterpret_cast<const uint4*>(sb + swz(i * 16 + lrow, lq));
+#pragma unroll
+    for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq));
+#pragma unroll
+    for (int i = 0; i < NT; ++i) gb[i] = *reinterpret_cast<const uint4*>(sb + swz(i * 16 + lrow, lq + 4));
+#pragma unroll
+    for (int i = 0; i < MT; ++i) ga[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq + 4));
+    if (t + 1 < nk) PP_ISSUE_B((t + 1) & 1);
+    if (t + 2 < nk) PP_ISSUE_A(t + 2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // every fragment is in registers: the stage may be refilled
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // ---------------- COMPUTE(t)
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], ga[i], gb[j]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the DMA issued in LOAD(t) has landed
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (grp == 0) asm volatile("s_barrier" ::: "memory");          // matches group 1's last COMPUTE barrier
+#undef PP_SET_ROWS
+#undef PP_ISSUE_B
+#undef PP_ISSUE_A
+  __syncthreads();
+
+  conv_epilogue<T, MT, NT, BM, BN, NTHR>(kp, acc, cm0, pn0, (int)blockIdx.y, wm, wn, lrow, lq, smem, bias_in_acc, 0, 0, 0);
+}
+
 // split-K second pass: fixed-order sum of the f32 slabs + the conv epilogue
 template <typename T>
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvP kp) {
@@ -683,13 +866,15 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvP kp)
 // split-K second pass that ALSO emits the GroupNorm strip statistics the fused epilogue would have written (per 64-pixel strip and
 // channel: sum and sum of squares of the stored, i.e. rounded, outputs).  Without it every split-K layer followed by a GroupNorm
 // costs two more passes (gn_partial + gn_coef): at the 8-candidates-per-GPU batch of a sharded search those were 2.6 ms of a
-// 15.9 ms iteration.  Block = one strip x 256 channels: thread = 4 channels x 16 pixels, then a fixed-order LDS reduction over the
-// four pixel groups (deterministic, no atomics).  Same arithmetic and order as conv_splitk_reduce_kernel.
+// 15.9 ms iteration.  Block = one strip x 64 channels, then a fixed-order LDS reduction over the sixteen pixel lanes
+// (deterministic, no atomics).  Same arithmetic and order per element as conv_splitk_reduce_kernel.
 template <typename T>
 __global__ __launch_bounds__(256) void conv_splitk_reduce_stats_kernel(const ConvP kp) {
-  __shared__ float red[4][64][8];
-  const int strip = blockIdx.x, cq = threadIdx.x & 63, pg = threadIdx.x >> 6;
-  const int co = (blockIdx.y * 64 + cq) * 4;
+  // thread = 4 channels x 4 pixels (pixel lane pl, pixels pl + 16 i of the strip): 16 quads x 16 B = one 256-byte segment per
+  // pixel row, four independent load chains per thread over the splits
+  __shared__ float red[16][16][8];
+  const int strip = blockIdx.x, q = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int co = (blockIdx.y * 16 + q) * 4;
   const bool live = co < kp.cout;
   const T* res = reinterpret_cast<const T*>(kp.residual);
   const T* bnc = reinterpret_cast<const T*>(kp.bias_nc);
@@ -697,39 +882,49 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_stats_kernel(const Con
   const int hw = kp.hout * kp.wout;
   float ss[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
   if (live) {
+    const int p0 = strip * 64 + pl;
+    float v[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f; }
+    for (int s_ = 0; s_ < kp.splits; ++s_) {             // fixed order over the splits (as conv_splitk_reduce_kernel)
+      const float* base = kp.partial + ((size_t)s_ * kp.P + p0) * kp.cout + co;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 t4 = *reinterpret_cast<const float4*>(base + (size_t)(16 * i) * kp.cout);
+        v[i][0] += t4.x; v[i][1] += t4.y; v[i][2] += t4.z; v[i][3] += t4.w;
+      }
+    }
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (kp.bias) bv = *reinterpret_cast<const float4*>(kp.bias + co);
-    const int p0 = strip * 64 + pg * 16;
-    const int ns = p0 / hw;                              // a strip never straddles two samples (hw % 64 == 0)
     float nb[4] = {0.f, 0.f, 0.f, 0.f};
-    if (bnc) Vec4<T>::load(bnc + (size_t)ns * kp.ld_bias_nc + co, nb);
-    for (int i = 0; i < 16; ++i) {
-      const int pp = p0 + i;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int s_ = 0; s_ < kp.splits; ++s_) {
-        const float4 q = *reinterpret_cast<const float4*>(kp.partial + ((size_t)s_ * kp.P + pp) * kp.cout + co);
-        v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
-      }
-      v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-      if (bnc) { for (int r = 0; r < 4; ++r) v[r] += nb[r]; }
+    if (bnc) Vec4<T>::load(bnc + (size_t)((strip * 64) / hw) * kp.ld_bias_nc + co, nb);    // a strip never straddles two samples
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pp = p0 + 16 * i;
+      v[i][0] += bv.x; v[i][1] += bv.y; v[i][2] += bv.z; v[i][3] += bv.w;
+      if (bnc) { for (int r = 0; r < 4; ++r) v[i][r] += nb[r]; }
       if (res) {
         float f[4];
         Vec4<T>::load(res + (size_t)pp * kp.cout + co, f);
-        for (int r = 0; r < 4; ++r) v[r] += f[r];
+        for (int r = 0; r < 4; ++r) v[i][r] += f[r];
       }
-      for (int r = 0; r < 4; ++r) v[r] *= kp.out_scale;
-      const typename Vec4<T>::type pk = Vec4<T>::pack(v);
+      for (int r = 0; r < 4; ++r) v[i][r] *= kp.out_scale;
+      const typename Vec4<T>::type pk = Vec4<T>::pack(v[i]);
       *reinterpret_cast<typename Vec4<T>::type*>(out + (size_t)pp * kp.cout + co) = pk;
       float f[4];
       Vec4<T>::unpack(pk, f);                            // moments of the values as stored
       for (int r = 0; r < 4; ++r) { ss[r] += f[r]; sq[r] += f[r] * f[r]; }
     }
   }
-  for (int r = 0; r < 4; ++r) { red[pg][cq][2 * r] = ss[r]; red[pg][cq][2 * r + 1] = sq[r]; }
+  for (int r = 0; r < 4; ++r) { red[pl][q][2 * r] = ss[r]; red[pl][q][2 * r + 1] = sq[r]; }
   __syncthreads();
-  if (pg == 0 && live) {
+  if (pl == 0 && live) {
     float o[8];
-    for (int j = 0; j < 8; ++j) o[j] = ((red[0][cq][j] + red[1][cq][j]) + red[2][cq][j]) + red[3][cq][j];
+    for (int j = 0; j < 8; ++j) {
+      float a_ = red[0][q][j];
+      for (int k = 1; k < 16; ++k) a_ += red[k][q][j];   // fixed order: deterministic
+      o[j] = a_;
+    }
     float4* d = reinterpret_cast<float4*>(kp.stats + ((size_t)strip * kp.cout + co) * 2);
     d[0] = make_float4(o[0], o[1], o[2], o[3]);
     d[1] = make_float4(o[4], o[5], o[6], o[7]);
@@ -779,7 +974,7 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, C
   DTS_CHECK_LAUNCH("dts_conv2d");
   if (splits > 1 && stats_in_reduce) {
     q.stats = stats_req;
-    hipLaunchKernelGGL((conv_splitk_reduce_stats_kernel<T>), dim3(p.P / 64, (p.cout + 255) / 256), dim3(256), 0, st, q);
+    hipLaunchKernelGGL((conv_splitk_reduce_stats_kernel<T>), dim3(p.P / 64, (p.cout + 63) / 64), dim3(256), 0, st, q);
     DTS_CHECK_LAUNCH("dts_conv2d(split-K reduce + statistics)");
   } else if (splits > 1) {
     long long g = ((long long)p.P * (p.cout / 4) + 255) / 256;
@@ -788,6 +983,61 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, C
     DTS_CHECK_LAUNCH("dts_conv2d(split-K reduce)");
   }
   return DTS_OK;
+}
+
+// ---- ping-pong launcher: one block per (192-cout tile, 256-pixel tile[, K split]); 512 threads, 136 KB of LDS
+template <typename T>
+int launch_conv_pp(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, ConvCall& call) {
+  if constexpr (sizeof(T) != 2) {
+    return DTS_ERR_UNSUPPORTED;
+  } else {
+    constexpr int BM = 192, BN = 256, BKE = 64;
+    ConvP q = p;
+    q.n_ct = p.cout / BM;
+    q.n_pt = (p.P + BN - 1) / BN;
+    const int nblk = q.n_ct * q.n_pt;
+    const int nk = p.taps * (p.cin / BKE);
+    int splits = 1;
+    const int forced = dts_knob_get(DTS_KNOB_CONV_SPLITS);
+    if (ws != nullptr && nk >= 16) {
+      if (forced > 0) splits = forced;
+      else if (nblk < 192) splits = (256 + nblk - 1) / nblk;     // one resident block per CU: fill 256 slots
+      if (splits > 8) splits = 8;
+      if (splits > nk / 8) splits = nk / 8;
+      while (splits > 1 && (long long)splits * p.P * p.cout * 4 > ws_bytes) --splits;
+      if (splits < 1) splits = 1;
+    }
+    q.ks_per_split = (nk + splits - 1) / splits;
+    splits = (nk + q.ks_per_split - 1) / q.ks_per_split;
+    q.splits = splits;
+    q.partial = ws;
+    float* const stats_req = p.stats;
+    const bool stats_in_reduce = splits > 1 && stats_req != nullptr && (p.hout * p.wout) % 64 == 0 && p.cout % 4 == 0;
+    if (splits > 1) q.stats = nullptr;
+    call.stats_written = q.stats != nullptr || stats_in_reduce;
+    constexpr size_t lds = (size_t)(3 * BM + 2 * BN) * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_done = true;
+    }
+    if (call.ev_start != nullptr && call.ev_stop != nullptr)
+      hipExtLaunchKernelGGL((conv_pp_kernel<T>), dim3(nblk, splits), dim3(512), lds, st, call.ev_start, call.ev_stop, 0, q);
+    else
+      hipLaunchKernelGGL((conv_pp_kernel<T>), dim3(nblk, splits), dim3(512), lds, st, q);
+    DTS_CHECK_LAUNCH("dts_conv2d(ping-pong)");
+    if (splits > 1 && stats_in_reduce) {
+      q.stats = stats_req;
+      hipLaunchKernelGGL((conv_splitk_reduce_stats_kernel<T>), dim3(p.P / 64, (p.cout + 63) / 64), dim3(256), 0, st, q);
+      DTS_CHECK_LAUNCH("dts_conv2d(split-K reduce + statistics)");
+    } else if (splits > 1) {
+      long long g = ((long long)p.P * (p.cout / 4) + 255) / 256;
+      if (g > 2048) g = 2048;
+      hipLaunchKernelGGL((conv_splitk_reduce_kernel<T>), dim3((int)g), dim3(256), 0, st, q);
+      DTS_CHECK_LAUNCH("dts_conv2d(split-K reduce)");
+    }
+    return DTS_OK;
+  }
 }
 
 template <typename T, bool PF>
@@ -803,6 +1053,15 @@ template <typename T>
 int conv_dispatch(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, ConvCall& call) {
   const int g_tile_override = dts_knob_get(DTS_KNOB_CONV_TILE);     // DTS_CONV_TILE=64|128|192 (tuning aid; only honoured when it divides cout)
   int tile = (p.cout % 192 == 0) ? 192 : (p.cout % 128 == 0 ? 128 : 64);    // measured: tools/conv_bench.py
+  // f32 (parity mode): the 192-cout tile needs 256 VGPRs and still spills 36 bytes per lane to scratch; take the next tile down
+  if (std::is_same<T, float>::value && tile == 192) tile = (p.cout % 128 == 0) ? 128 : 64;
+  // DTS_CONV_VARIANT: 1 = the 8-wave ping-pong kernel wherever it applies (16-bit, cout % 192 == 0), 0 = never, unset = by shape
+  const int variant = dts_knob_get(DTS_KNOB_CONV_VARIANT);
+  if (!std::is_same<T, float>::value && p.cout % 192 == 0 && g_tile_override <= 0) {
+    const long long blocks_pp = (long long)(p.cout / 192) * ((p.P + 255) / 256);
+    const bool auto_pp = false;                                   // (set from measurements: tools/conv_bench.py --variants)
+    if (variant == 1 || (variant < 0 && auto_pp && blocks_pp >= 256)) return launch_conv_pp<T>(p, st, ws, ws_bytes, call);
+  }
   if (g_tile_override > 0 && p.cout % g_tile_override == 0) tile = g_tile_override;
   // fragment prefetch pays on the long K loops of the 3x3 layers; f32 (parity mode) keeps the lean order: its 192-cout
   // tile is already at the 256-VGPR limit

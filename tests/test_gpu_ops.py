@@ -109,7 +109,7 @@ def test_conv2d_big_tiles(ops, dtype):
 @pytest.mark.parametrize('dtype', DTYPES)
 def test_conv_epilogue_emits_group_norm_statistics(ops, dtype):
     """the GroupNorm moments fused into the conv epilogue give the same normalisation as the standalone pass,
-    for single and concatenated sources, and are withheld (None) when the launch takes the split-K path."""
+    for single and concatenated sources; a split-K launch emits them from its reduce pass."""
     gen = g(21)
     n, h, w, c, cout = 2, 16, 16, 64, 128
     x = q(torch.randn(n, c, h, w, generator=gen), dtype)
@@ -128,11 +128,22 @@ def test_conv_epilogue_emits_group_norm_statistics(ops, dtype):
     assert rel_err(a.float().cpu(), b.float().cpu()) < (1e-5 if dtype == torch.float32 else 2e-2)
     ref = onet.silu(onet.group_norm(torch.cat([from_nhwc(ops, y1), from_nhwc(ops, y2)], 1), gamma, beta, 1e-5))
     assert rel_err(from_nhwc(ops, a), ref) < (2e-5 if dtype == torch.float32 else TOL[dtype])
-    # split-K launch (1 tile, long K): statistics are not produced and the caller falls back
-    xs = q(torch.randn(1, 256, 8, 8, generator=gen), dtype)
+    # split-K launch (few tiles, long K): the statistics come from the reduce pass (residual + bias + scale included)
+    xs = q(torch.randn(2, 256, 8, 8, generator=gen), dtype)
     ws = q(torch.randn(128, 256, 3, 3, generator=gen) / 48, dtype)
-    ys = ops.conv2d(to_nhwc(ops, xs, dtype), ops.pack_conv_weight(ws.to(DEV), dtype), None, gn_stats=True)
-    assert ys._gn_stats is None
+    rs = q(torch.randn(2, 128, 8, 8, generator=gen), dtype)
+    bs = torch.randn(128, generator=gen)
+    ys = ops.conv2d(to_nhwc(ops, xs, dtype), ops.pack_conv_weight(ws.to(DEV), dtype), bs.to(DEV), residual=to_nhwc(ops, rs, dtype),
+                    out_scale=0.7, gn_stats=True)
+    assert ys._gn_stats is not None and tuple(ys._gn_stats.shape) == (2, 128, 2)
+    yf = ys.float().reshape(2, 64, 128)
+    want = torch.stack([yf.sum(1), (yf * yf).sum(1)], dim=-1)              # per (sample = strip, channel): sum, sum of squares
+    assert rel_err(ys._gn_stats.cpu(), want.cpu()) < 1e-5
+    g2, b2 = torch.randn(128, generator=gen), torch.randn(128, generator=gen)
+    a2 = ops.group_norm(ys, 32, 1e-5, g2.to(DEV), b2.to(DEV), path='strips')
+    ys._gn_stats = None
+    b2_ = ops.group_norm(ys, 32, 1e-5, g2.to(DEV), b2.to(DEV), path='split')
+    assert rel_err(a2.float().cpu(), b2_.float().cpu()) < (1e-5 if dtype == torch.float32 else 2e-2)
 
 
 def test_conv2d_identical_rows_are_bit_identical(ops):

@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Per-shape throughput of dts_conv2d on the ADM-64 / classifier layer shapes (tuning harness, GPU box only).
-Times each shape with HIP events (GPU kept busy ahead of the measured launch) and prints TFLOP/s."""
+Times each shape with HIP events (GPU kept busy ahead of the measured launch) and prints TFLOP/s.  `--variants` times kernel
+variants (tuning knobs, dts_set_tuning) INTERLEAVED in one process, round by round, on random data, and checks that every variant
+produces bit-identical outputs:   python tools/conv_bench.py --stats --variants conv_variant=0 conv_variant=1"""
 import argparse
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from diffusion_tts_amd import ops
+from diffusion_tts_amd import ops, _lib
 
 SHAPES = [  # (name, res, cin, cout, k)
     ('L0 3x3 192->192', 64, 192, 192, 3), ('L0 3x3 384->192', 64, 384, 192, 3), ('L0 1x1 384->192', 64, 384, 192, 1),
@@ -22,7 +24,11 @@ def main():
     ap.add_argument('--dtype', default='bf16')
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--stats', action='store_true', help='also emit the fused GroupNorm strip statistics (as the network does)')
+    ap.add_argument('--no-res', action='store_true', help='no residual input')
+    ap.add_argument('--variants', nargs='*', default=None, help='e.g. conv_variant=0 conv_variant=1 (interleaved A/B)')
     a = ap.parse_args()
+    if a.variants:
+        return ab(a)
     dt = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[a.dtype]
     dev = 'cuda'
     tot_f = tot_t = 0.0
@@ -50,6 +56,45 @@ def main():
         tot_t += ms
         print(f'{name:22s} P={a.n*r*r:7d} K={cin*k*k:6d}  {ms*1e3:8.1f} us  {fl/ms/1e9:8.1f} TFLOP/s', flush=True)
     print(f'unweighted total: {tot_f/tot_t/1e9:.1f} TFLOP/s')
+
+
+def ab(a):
+    dt = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[a.dtype]
+    variants = [dict((kv.split('=')[0], int(kv.split('=')[1])) for kv in v.split(',')) for v in a.variants]
+    tot = [[0.0, 0.0] for _ in variants]
+    for name, r, cin, cout, k in SHAPES:
+        x = torch.randn(a.n, r, r, cin, device='cuda').to(dt)
+        w = (torch.randn(cout, k, k, cin, device='cuda') / (cin * k * k) ** 0.5).to(dt)
+        b = torch.randn(cout, device='cuda')
+        res = None if a.no_res else torch.randn(a.n, r, r, cout, device='cuda').to(dt)
+        outs = [torch.empty(a.n, r, r, cout, device='cuda', dtype=dt) for _ in variants]
+        ts = [[] for _ in variants]
+        stats = [None] * len(variants)
+        for rnd in range(a.iters + 1):
+            for vi, v in enumerate(variants):
+                for kk, val in v.items():
+                    _lib.set_tuning(kk, val)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda._sleep(200_000)
+                e0.record()
+                o = ops.conv2d(x, w, b, residual=res, out=outs[vi], gn_stats=a.stats)
+                e1.record()
+                torch.cuda.synchronize()
+                stats[vi] = o._gn_stats
+                if rnd:
+                    ts[vi].append(e0.elapsed_time(e1))
+                for kk in v:
+                    _lib.set_tuning(kk, -1)
+        fl = 2.0 * a.n * r * r * cout * cin * k * k
+        same = all(torch.equal(outs[0], o) for o in outs[1:])
+        same_st = all((stats[0] is None) == (s_ is None) and (s_ is None or torch.allclose(stats[0], s_, rtol=1e-5, atol=1e-3)) for s_ in stats[1:])
+        row = f'{name:22s} P={a.n * r * r:7d} K={cin * k * k:6d}'
+        for vi in range(len(variants)):
+            ms = sorted(ts[vi])[len(ts[vi]) // 2]
+            tot[vi][0] += fl; tot[vi][1] += ms
+            row += f' | {a.variants[vi]}: {ms * 1e3:7.1f} us {fl / ms / 1e9:7.1f} TF/s'
+        print(row + f' | outputs {"identical" if same else "DIFFER"}, stats {"ok" if same_st else "DIFFER"}', flush=True)
+    print('unweighted totals: ' + ' | '.join(f'{a.variants[vi]}: {tot[vi][0] / tot[vi][1] / 1e9:.1f} TF/s' for vi in range(len(variants))))
 
 
 if __name__ == '__main__':

@@ -1,0 +1,6 @@
+#!/bin/bash
+set -o pipefail
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2f; mkdir -p $O
+DTS_CONV_VARIANT=1 timeout -k 10 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -x --timeout 500 > $O/pytest_pp.log 2>&1; echo "rc=$?"; tail -4 $O/pytest_pp.log
+timeout -k 10 300 python tools/conv_bench.py --n 64 --stats --variants conv_variant=0 conv_variant=1 > $O/conv_ab.txt 2>&1; cat $O/conv_ab.txt
+timeout -k 10 300 python tools/conv_bench.py --n 64 --stats --no-res --variants conv_variant=0 conv_variant=1 > $O/conv_ab_nores.txt 2>&1; cat $O/conv_ab_nores.txt
