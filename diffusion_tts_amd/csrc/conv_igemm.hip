@@ -142,6 +142,22 @@ __device__ __forceinline__ void glds16(const char* g, uint32_t lds_off) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_off) : "memory", "m0");
 }
 
+// LDS-DMA through a buffer descriptor: per-lane 32-bit byte offset + wave-uniform SGPR offset.  Two things the flat form above
+// cannot do: (1) the K advance is ONE scalar add per tile for all rows of an operand instead of a 64-bit vector add per row
+// (the LOAD segment of the ping-pong kernel competes with its SIMD partner's MFMAs for vector issue slots, so every VALU
+// instruction removed from it counts double); (2) an offset at or beyond num_records reads as zero, so out-of-image (padding)
+// rows need no zero page and no pointer select: their lane offset is simply out of range.
+typedef int dts_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ dts_i32x4 make_rsrc(const void* base, uint32_t bytes) {
+  const uint64_t a = (uint64_t)(uintptr_t)base;
+  return dts_i32x4{(int)(uint32_t)a, (int)(uint32_t)(a >> 32), (int)bytes, 0x00020000};     // raw buffer: stride 0, num_records in bytes
+}
+__device__ __forceinline__ void bdma16(uint32_t voff, dts_i32x4 rsrc, uint32_t soff, uint32_t lds_off) {
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+               : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_off) : "memory", "m0");
+}
+constexpr uint32_t DTS_OOR = 0x80000000u;      // lane offset beyond any tensor here (< 2 GiB each): reads as zeros
+
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
 // LDS-DMA pieces [u0, u1) of the residual tile into the staged tile at LDS byte address `stage` (wave-uniform): piece u is the
@@ -365,7 +381,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
   // stores 16 contiguous bytes and a wave-instruction covers 1 KiB of whole output rows.
   constexpr bool VIA_LDS = sizeof(T) == 2;
   constexpr int ROWP = BM * 2 + 16;                    // LDS row pitch of the staged tile (pixel-major), bytes
-  static_assert(!VIA_LDS || BN * ROWP <= (NTHR == 256 ? 2 * (BM + BN) * 128 : (3 * BM + 2 * BN) * 128), "staged tile must fit the ring");
+  static_assert(!VIA_LDS || BN * ROWP <= (NTHR == 256 ? 2 * (BM + BN) * 128 : (5 * 96 + 3 * BN) * 128), "staged tile must fit the ring");
   const bool want_stats = NT == 4 && kp.stats != nullptr;
   float* sp = want_stats ? kp.stats + ((size_t)((pn0 + wn * 64) >> 6) * p_cout) * 2 : nullptr;
 #pragma unroll
@@ -659,20 +675,29 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
 // wide in pixels, so a K step moves 7 LDS-DMA pieces per wave instead of 10 (the weight rows are shared by 256 pixels).
 //
 // Work split: wave = (group g, index i): couts wm*96.. (wm = i & 1), pixels wn*64.. (wn = 2g + (i >> 1)).  Group g therefore reads
-// only pixel half g of the activation tile -> the B halves are private to a group (2 stages each, filled by that group one tile
-// ahead); the weight tile A is read by both groups (3 stages, each group fills its 96 rows two tiles ahead).
-//   LDS: A 3 x 24 KB | B 2 stages x 2 halves x 16 KB = 136 KB.
-// Ordering (segments numbered s; group 0: LOAD(t) = 2t, COMPUTE(t) = 2t+1; group 1 one later):
-//   * a wave's LDS reads are complete (lgkmcnt(0)) before the barrier that ends its LOAD segment;
-//   * a wave's LDS-DMA is complete (vmcnt(0)) before the barrier that ends the NEXT segment (its COMPUTE);
-//   * B_g(t+1) is issued in LOAD(t) into the stage last read in LOAD(t-1) by the same group, read in LOAD(t+1);
-//   * A(t+2) is issued in LOAD(t) (segments 2t, 2t+1) into the stage of A(t-1), last read in segment 2t-1; first read in 2t+4.
+// only pixel half g of the activation tile: the B halves are PRIVATE to a group; the weight tile A is read by both groups.
+// LDS-DMA distance (timing-only builds, profiles/r02_conv_variants.txt: without DMA the loop runs 18 % faster, and a DMA waited for one
+// segment after its issue is what set the pace): activation rows come from beyond the XCD's L2 (a CU's 3x3 halo of a 256-pixel tile
+// is 0.1-0.5 MB, 32 CUs share 4 MB), weight rows are L2 hits.  So
+//   * B_g: 3 stages x 16 KB per group; B_g(t+2) is issued in LOAD(t) into the stage of B_g(t-1) (last read in LOAD(t-1) by the same
+//     group) and is first read in LOAD(t+2): four segments of flight;
+//   * A rows 0-95 (filled by group 0): 2 stages x 12 KB; A0(t+1) is issued in group 0's LOAD(t) (segment 2t) into the stage of
+//     A0(t-1), last read by group 1 in segment 2t-1, complete before the barrier ending segment 2t+1, first read in segment 2t+2;
+//   * A rows 96-191 (filled by group 1): 3 stages x 12 KB; A1(t+2) is issued in group 1's LOAD(t) (segment 2t+1) into the stage of
+//     A1(t-1), last read in segment 2t-1, complete before the barrier ending segment 2t+2, first read in segment 2t+4.
+//   LDS: A0 2 x 12 KB | A1 3 x 12 KB | B 3 stages x 2 halves x 16 KB = 156 KB.
+// Waits: a wave's fragment reads are complete (lgkmcnt(0)) before the barrier that ends its LOAD segment; within a LOAD segment
+// the A pieces are issued BEFORE the B pieces, and the barrier that ends the following COMPUTE segment is preceded by vmcnt(4):
+// everything but the four youngest pieces -- B_g(t+2) -- has landed, i.e. B_g(t+1) and the A pieces just issued.
 // Accumulation order over K is that of conv_igemm_kernel (tap-major, 64 channels per step, two 32-deep MFMAs): bit-identical outputs.
-template <typename T>
+// DBG != 0: timing-only diagnostic builds (outputs wrong by construction; tools/conv_bench.py conv_variant=11/21/31):
+//   1 = no LDS-DMA after the prologue, 2 = no MFMAs, 3 = no fragment reads, 4 = every B piece out of range (zeros: the instruction
+//   issues and writes LDS but fetches nothing), 5 = every A piece out of range
+template <typename T, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
   constexpr int MT = 6, NT = 4, BM = 192, BN = 256, NTHR = 512;
   constexpr int BKE = 64, ES = 2;
-  constexpr int A_STAGE = BM * 128, B_HALF = 128 * 128, B_OFF = 3 * A_STAGE;
+  constexpr int A_HALF = 96 * 128, B_HALF = 128 * 128, A1_OFF = 2 * A_HALF, B_OFF = 5 * A_HALF;     // see the LDS map above
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const char* const p_x1 = kp.x1; const char* const p_x2 = kp.x2; const char* const p_w = kp.w;
   const int p_c1 = kp.c1, p_c2 = kp.c2, p_cin = kp.cin, p_win = kp.win, p_hout = kp.hout, p_wout = kp.wout;
@@ -695,28 +720,45 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
   const int lrow = lane & 15, lq = lane >> 4;
 
   const int K = p_taps * p_cin;
-  const int steps_per_tap = p_cin / BKE;
-  const int nk_all = p_taps * steps_per_tap;
+  const int nk_all = p_taps * (p_cin / BKE);
   const int ks_begin = blockIdx.y * kp.ks_per_split;
   const int ks_end = min(nk_all, ks_begin + kp.ks_per_split);
   const int nk = ks_end - ks_begin;
 
   const int schunk = (chunk ^ (r0 & 7)) * 16;
-  const char* zsrc = reinterpret_cast<const char*>(g_zero16);
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
-  // ---- this lane's rows: A share = rows grp*96 + 8*(wi + 4j) + r0 (j < 3), B share = rows 8*(wi + 4j) + r0 of half grp (j < 4)
-  const char* arow[3];
+  // ---- this lane's rows: A share = rows grp*96 + 8*(wi + 4j) + r0 (j < 3), B share = rows 8*(wi + 4j) + r0 of half grp (j < 4).
+  // Addresses are (descriptor, 32-bit lane offset, scalar offset).
+  //
+  // K ORDER: channel chunk outer, tap inner (k tile kt = chunk * taps + tap).  conv_igemm_kernel walks K tap-major, so the 9 taps that
+  // re-read (nearly) the same 64-channel slice of the same pixel rows are a whole cin sweep apart -- hundreds of KB per CU, 32 CUs per
+  // 4 MB L2 -- and every one of the 9 reads came from beyond L2 (timing-only builds: with the activation pieces out of range the loop
+  // ran 25 % faster, with the weight pieces out of range 16 %; profiles/r02_conv_variants.txt).  Tap-inner order makes 8 of the 9
+  // reads L2 hits.  With it the tap is a UNIFORM byte delta (dh*win + dw) * cs * ES on top of a per-lane base that never changes:
+  // it lives in the scalar offset (the descriptor base is moved back by one row + one pixel so that the deltas are non-negative),
+  // and the image border is a 9-bit validity mask per row: an invalid (padding) row gets an out-of-range lane offset = zeros.
+  // Weights are stored [cout][tap][cin]: the A tile of (chunk, tap) is at byte (tap*cin + chunk*64) * ES of each row.
+  // The summation order over K therefore differs from conv_igemm_kernel's (same terms, different f32 rounding order); it is fixed,
+  // so identical inputs still give identical outputs.  The fused nearest-2x upsample is not a uniform delta: those layers stay on
+  // conv_igemm_kernel (launcher).
+  const int hw_in = kp.hin * p_win;
+  const uint32_t sh1 = (uint32_t)(p_win + 1) * p_c1 * ES, sh2 = (uint32_t)(p_win + 1) * p_c2 * ES;
+  const dts_i32x4 rs_w = make_rsrc(p_w, (uint32_t)((size_t)kp.cout * K * ES));
+  const dts_i32x4 rs_x1 = make_rsrc(p_x1 - sh1, (uint32_t)((size_t)kp.n * hw_in * p_c1 * ES) + sh1);
+  const dts_i32x4 rs_x2 = make_rsrc(p_x2 ? p_x2 - sh2 : p_x1, p_x2 ? (uint32_t)((size_t)kp.n * hw_in * p_c2 * ES) + sh2 : 0u);
+  uint32_t avo[3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j)
-    arow[j] = p_w + ((size_t)(cm0 + grp * 96 + 8 * (wi + 4 * j) + r0) * K + (size_t)ks_begin * BKE) * ES + schunk;
-  const uint32_t a_dst = lds_base + (grp * 96 + 8 * wi) * 128;                   // + j*32*128 + stage*A_STAGE
+  for (int j = 0; j < 3; ++j) avo[j] = DBG == 5 ? DTS_OOR : (uint32_t)((cm0 + grp * 96 + 8 * (wi + 4 * j) + r0) * K) * ES + schunk;
+  const uint32_t a_dst = lds_base + grp * A1_OFF + (8 * wi) * 128;               // + j*32*128 + stage*A_HALF (group g fills ring g)
   const uint32_t b_dst = lds_base + B_OFF + grp * B_HALF + (8 * wi) * 128;       // + j*32*128 + stage*2*B_HALF
 
-  int pix_n[4], pix_hw[4];
+  int pixoff[4];                                       // source pixel index n*hin*win + h*win + w of the row's centre tap (-1: no pixel)
+  uint32_t vmask[4];                                   // bit t: tap t of this row is inside the image
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int pp = pn0 + grp * 128 + 8 * (wi + 4 * j) + r0;
+    pixoff[j] = -1; vmask[j] = 0;
     if (pp < p_P) {
       int n, ho, wo;
       if (kp.hw_shift >= 0) {
@@ -729,41 +771,50 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
         const int rem = pp - n * hw;
         ho = rem / p_wout; wo = rem - ho * p_wout;
       }
-      pix_n[j] = n * kp.hin * p_win;
-      pix_hw[j] = (ho << 16) | wo;
-    } else {
-      pix_n[j] = -1;
-      pix_hw[j] = 0;
+      pixoff[j] = n * hw_in + ho * p_win + wo;
+      if (p_taps == 9) {
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9) {
+          const int hu = ho + t9 / 3 - 1, wu = wo + t9 % 3 - 1;
+          if ((unsigned)hu < (unsigned)p_hout && (unsigned)wu < (unsigned)p_wout) vmask[j] |= 1u << t9;
+        }
+      } else {
+        vmask[j] = 1u;
+      }
     }
   }
-  const char* brow[4];
-  int tap = ks_begin / steps_per_tap, ci0 = (ks_begin - tap * steps_per_tap) * BKE;      // K position of the NEXT B tile to issue
-
-#define PP_SET_ROWS(tap_, ci0_)                                                                               \
+  uint32_t bvo[4];                                     // centre-tap lane offsets of the B rows in the current source
+  // K position of the NEXT B tile to issue, in (chunk, tap) order
+  int kt_b = ks_begin;
+  int tap = kt_b % p_taps, ci0 = (kt_b / p_taps) * BKE;
+  bool b_src2 = ci0 >= p_c1;
+#define PP_SET_SRC()                                                                                          \
   {                                                                                                           \
-    const int dh_ = (p_taps == 9) ? (tap_) / 3 - 1 : 0, dw_ = (p_taps == 9) ? (tap_) % 3 - 1 : 0;             \
-    const char* xb; int cs, cofs;                                                                             \
-    if ((ci0_) < p_c1) { xb = p_x1; cs = p_c1; cofs = (ci0_); } else { xb = p_x2; cs = p_c2; cofs = (ci0_) - p_c1; } \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                           \
-      const int hu = (pix_hw[j] >> 16) + dh_, wu = (pix_hw[j] & 0xffff) + dw_;                                \
-      const bool ok = pix_n[j] >= 0 && (unsigned)hu < (unsigned)p_hout && (unsigned)wu < (unsigned)p_wout;    \
-      const int hs = p_up ? (hu >> 1) : hu, ws = p_up ? (wu >> 1) : wu;                                       \
-      brow[j] = ok ? xb + ((size_t)(pix_n[j] + hs * p_win + ws) * cs + cofs) * ES + schunk : zsrc;            \
-    }                                                                                                         \
+    b_src2 = ci0 >= p_c1;                                                                                     \
+    const int cs_ = b_src2 ? p_c2 : p_c1;                                                                     \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                             \
+      bvo[j] = (pixoff[j] >= 0 && DBG != 4) ? (uint32_t)(pixoff[j] * cs_) * ES + schunk : DTS_OOR;            \
   }
 #define PP_ISSUE_B(stage_)                                                                                    \
   {                                                                                                           \
     const uint32_t d_ = b_dst + (stage_) * (2 * B_HALF);                                                      \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) glds16(brow[j], d_ + j * (32 * 128));                       \
-    ci0 += BKE;                                                                                               \
-    if (ci0 == p_cin) { ci0 = 0; ++tap; if (tap < p_taps) PP_SET_ROWS(tap, 0); }                              \
-    else if (ci0 == p_c1) { PP_SET_ROWS(tap, ci0); }                                                          \
-    else { _Pragma("unroll") for (int j = 0; j < 4; ++j) brow[j] += BKE * ES; }                               \
+    const int cs_ = b_src2 ? p_c2 : p_c1;                                                                     \
+    const int dlt_ = (p_taps == 9) ? ((tap / 3) * p_win + tap % 3) : (p_win + 1);      /* (dh+1)*win + (dw+1) */ \
+    const uint32_t so_ = (uint32_t)(dlt_ * cs_ + (b_src2 ? ci0 - p_c1 : ci0)) * ES;                           \
+    const uint32_t bit_ = 1u << tap;                                                                          \
+    if (b_src2) { _Pragma("unroll") for (int j = 0; j < 4; ++j) bdma16((vmask[j] & bit_) ? bvo[j] : DTS_OOR, rs_x2, so_, d_ + j * (32 * 128)); } \
+    else        { _Pragma("unroll") for (int j = 0; j < 4; ++j) bdma16((vmask[j] & bit_) ? bvo[j] : DTS_OOR, rs_x1, so_, d_ + j * (32 * 128)); } \
+    if (++tap == p_taps) { tap = 0; ci0 += BKE; if (ci0 == p_c1) PP_SET_SRC(); }                              \
   }
-#define PP_ISSUE_A(t_)                                                                                        \
+  int a_tap = ks_begin % p_taps, a_ci0 = (ks_begin / p_taps) * BKE;       // K position of the NEXT A tile this wave issues
+  int a_stage = 0;                                                         // its ring slot (2 slots for group 0, 3 for group 1)
+#define PP_ISSUE_A()     /* this group's 96 rows of the next A tile */                                         \
   {                                                                                                           \
-    const uint32_t d_ = a_dst + ((t_) % 3) * A_STAGE;                                                         \
-    _Pragma("unroll") for (int j = 0; j < 3; ++j) glds16(arow[j] + (size_t)(t_) * (BKE * ES), d_ + j * (32 * 128)); \
+    const uint32_t d_ = a_dst + a_stage * A_HALF;                                                             \
+    const uint32_t so_ = (uint32_t)(a_tap * p_cin + a_ci0) * ES;                                              \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) bdma16(avo[j], rs_w, so_, d_ + j * (32 * 128));             \
+    if (++a_tap == p_taps) { a_tap = 0; a_ci0 += BKE; }                                                       \
+    if (++a_stage == (grp ? 3 : 2)) a_stage = 0;                                                              \
   }
 
   const bool bias_in_acc = kp.splits == 1 && kp.bias != nullptr;
@@ -776,52 +827,72 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{b0.x, b0.y, b0.z, b0.w};
   }
 
-  // ---- prologue: A(0), A(1), B_g(0)
-  PP_ISSUE_A(0);
-  if (nk > 1) PP_ISSUE_A(1);
-  PP_SET_ROWS(tap, ci0);
+  // ---- prologue: group 0: A0(0); group 1: A1(0), A1(1); both: B_g(0), B_g(1)
+  PP_ISSUE_A();
+  if (grp == 1 && nk > 1) PP_ISSUE_A();
+  PP_SET_SRC();
   PP_ISSUE_B(0);
+  if (nk > 1) PP_ISSUE_B(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_barrier" ::: "memory");
   if (grp == 1) asm volatile("s_barrier" ::: "memory");          // the stagger: group 1 runs one segment behind group 0
 
   for (int t = 0; t < nk; ++t) {
-    // ---------------- LOAD(t): fragments of tile t -> registers; DMA for B_g(t+1) and this group's rows of A(t+2)
-    const char* sa = smem + (t % 3) * A_STAGE + (wm * 96) * 128;
-    const char* sb = smem + B_OFF + ((t & 1) * 2 + grp) * B_HALF + ((wn & 1) * 64) * 128;
+    // ---------------- LOAD(t): fragments of tile t -> registers; DMA: this group's A rows (one / two tiles ahead), then B_g(t+2)
+    const char* sa = smem + (wm ? A1_OFF + (t % 3) * A_HALF : (t & 1) * A_HALF);
+    const char* sb = smem + B_OFF + ((t % 3) * 2 + grp) * B_HALF + ((wn & 1) * 64) * 128;
     uint4 fa[MT], fb[NT], ga[MT], gb[NT];
+    if constexpr (DBG == 3) {
 #pragma unroll
-    for (int i = 0; i < NT; ++i) fb[i] = *reinterpret_cast<const uint4*>(sb + swz(i * 16 + lrow, lq));
+      for (int i = 0; i < NT; ++i) { fb[i] = make_uint4(t, i, 1, 2); gb[i] = make_uint4(i, t, 3, 4); }
 #pragma unroll
-    for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq));
+      for (int i = 0; i < MT; ++i) { fa[i] = make_uint4(t, i, 5, 6); ga[i] = make_uint4(i, t, 7, 8); }
+    } else {
 #pragma unroll
-    for (int i = 0; i < NT; ++i) gb[i] = *reinterpret_cast<const uint4*>(sb + swz(i * 16 + lrow, lq + 4));
+      for (int i = 0; i < NT; ++i) fb[i] = *reinterpret_cast<const uint4*>(sb + swz(i * 16 + lrow, lq));
 #pragma unroll
-    for (int i = 0; i < MT; ++i) ga[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq + 4));
-    if (t + 1 < nk) PP_ISSUE_B((t + 1) & 1);
-    if (t + 2 < nk) PP_ISSUE_A(t + 2);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // every fragment is in registers: the stage may be refilled
+      for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq));
+#pragma unroll
+      for (int i = 0; i < NT; ++i) gb[i] = *reinterpret_cast<const uint4*>(sb + swz(i * 16 + lrow, lq + 4));
+#pragma unroll
+      for (int i = 0; i < MT; ++i) ga[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq + 4));
+    }
+    const bool more_b = t + 2 < nk;
+    if constexpr (DBG != 1) {
+      if (t + 1 + grp < nk) PP_ISSUE_A();                      // group 0: A0(t+1); group 1: A1(t+2)
+      if (more_b) PP_ISSUE_B((t + 2) % 3);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // every fragment is in registers: the stages may be refilled
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     // ---------------- COMPUTE(t)
     __builtin_amdgcn_s_setprio(1);
+    if constexpr (DBG == 2) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+      for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(fa[i].x), "v"(ga[i].w));
 #pragma unroll
-      for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
+      for (int i = 0; i < NT; ++i) asm volatile("" ::"v"(fb[i].x), "v"(gb[i].w));
+    } else {
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], ga[i], gb[j]);
+        for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], ga[i], gb[j]);
+    }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the DMA issued in LOAD(t) has landed
+    // all but the four youngest pieces (B_g(t+2), issued last in LOAD(t)) have landed: B_g(t+1) and this group's A pieces
+    if (more_b && DBG != 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   }
   if (grp == 0) asm volatile("s_barrier" ::: "memory");          // matches group 1's last COMPUTE barrier
-#undef PP_SET_ROWS
+#undef PP_SET_SRC
 #undef PP_ISSUE_B
 #undef PP_ISSUE_A
   __syncthreads();
@@ -986,7 +1057,7 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, C
 }
 
 // ---- ping-pong launcher: one block per (192-cout tile, 256-pixel tile[, K split]); 512 threads, 136 KB of LDS
-template <typename T>
+template <typename T, int DBG = 0>
 int launch_conv_pp(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, ConvCall& call) {
   if constexpr (sizeof(T) != 2) {
     return DTS_ERR_UNSUPPORTED;
@@ -1015,16 +1086,16 @@ int launch_conv_pp(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes
     const bool stats_in_reduce = splits > 1 && stats_req != nullptr && (p.hout * p.wout) % 64 == 0 && p.cout % 4 == 0;
     if (splits > 1) q.stats = nullptr;
     call.stats_written = q.stats != nullptr || stats_in_reduce;
-    constexpr size_t lds = (size_t)(3 * BM + 2 * BN) * 128;
+    constexpr size_t lds = (size_t)(5 * 96 + 3 * BN) * 128;       // A0 2 x 96 rows, A1 3 x 96 rows, B 3 x 256 rows of 128 bytes
     static bool attr_done = false;
     if (!attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<T, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_done = true;
     }
     if (call.ev_start != nullptr && call.ev_stop != nullptr)
-      hipExtLaunchKernelGGL((conv_pp_kernel<T>), dim3(nblk, splits), dim3(512), lds, st, call.ev_start, call.ev_stop, 0, q);
+      hipExtLaunchKernelGGL((conv_pp_kernel<T, DBG>), dim3(nblk, splits), dim3(512), lds, st, call.ev_start, call.ev_stop, 0, q);
     else
-      hipLaunchKernelGGL((conv_pp_kernel<T>), dim3(nblk, splits), dim3(512), lds, st, q);
+      hipLaunchKernelGGL((conv_pp_kernel<T, DBG>), dim3(nblk, splits), dim3(512), lds, st, q);
     DTS_CHECK_LAUNCH("dts_conv2d(ping-pong)");
     if (splits > 1 && stats_in_reduce) {
       q.stats = stats_req;
@@ -1057,10 +1128,17 @@ int conv_dispatch(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes,
   if (std::is_same<T, float>::value && tile == 192) tile = (p.cout % 128 == 0) ? 128 : 64;
   // DTS_CONV_VARIANT: 1 = the 8-wave ping-pong kernel wherever it applies (16-bit, cout % 192 == 0), 0 = never, unset = by shape
   const int variant = dts_knob_get(DTS_KNOB_CONV_VARIANT);
-  if (!std::is_same<T, float>::value && p.cout % 192 == 0 && g_tile_override <= 0) {
+  const bool pp_ok = !p.up && (long long)p.n * p.hin * p.win * (p.c1 > p.c2 ? p.c1 : p.c2) * 2 < (1ll << 31) - (1 << 20) &&
+                     (long long)p.cout * p.taps * p.cin * 2 < (1ll << 31);      // 32-bit lane offsets; uniform tap deltas
+  if (!std::is_same<T, float>::value && p.cout % 192 == 0 && g_tile_override <= 0 && pp_ok) {
     const long long blocks_pp = (long long)(p.cout / 192) * ((p.P + 255) / 256);
     const bool auto_pp = false;                                   // (set from measurements: tools/conv_bench.py --variants)
     if (variant == 1 || (variant < 0 && auto_pp && blocks_pp >= 256)) return launch_conv_pp<T>(p, st, ws, ws_bytes, call);
+    if (variant == 11) return launch_conv_pp<T, 1>(p, st, ws, ws_bytes, call);     // timing-only diagnostics
+    if (variant == 21) return launch_conv_pp<T, 2>(p, st, ws, ws_bytes, call);
+    if (variant == 31) return launch_conv_pp<T, 3>(p, st, ws, ws_bytes, call);
+    if (variant == 41) return launch_conv_pp<T, 4>(p, st, ws, ws_bytes, call);
+    if (variant == 51) return launch_conv_pp<T, 5>(p, st, ws, ws_bytes, call);
   }
   if (g_tile_override > 0 && p.cout % g_tile_override == 0) tile = g_tile_override;
   // fragment prefetch pays on the long K loops of the 3x3 layers; f32 (parity mode) keeps the lean order: its 192-cout
