@@ -160,17 +160,31 @@ constexpr uint32_t DTS_OOR = 0x80000000u;      // lane offset beyond any tensor 
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
+// Pixel rows of a block's output tile.  Linear tiles (conv_igemm_kernel; ping-pong kernel at W <= 16): row r is pixel pn0 + r of the
+// NHWC tensor.  Patch tiles (ping-pong kernel at W >= 32): the tile is a 16 x 16 pixel patch of one image, row r is patch pixel
+// (r >> 4, r & 15).  A 64-row wave strip of either kind lies inside one sample, which is all the GroupNorm strip statistics need.
+struct TileMap {
+  int pn0;          // first pixel (linear) -- also the patch's tile index * 256, for "whole tile inside P" tests
+  int patch;        // 0 linear, 1 patch
+  int porg;         // patch: pixel index of the patch's top-left corner
+  int w;            // patch: image width
+  int strip0;       // index of the tile's first 64-pixel strip in the statistics buffer
+  __device__ __forceinline__ int pix(int r) const { return patch ? porg + (r >> 4) * w + (r & 15) : pn0 + r; }
+  __device__ __forceinline__ int strip(int wn) const { return strip0 + wn; }
+};
+__device__ __forceinline__ TileMap linear_tile(int pn0) { return TileMap{pn0, 0, 0, 0, pn0 >> 6}; }
+
 // LDS-DMA pieces [u0, u1) of the residual tile into the staged tile at LDS byte address `stage` (wave-uniform): piece u is the
 // 16-byte slots u*NTHR .. u*NTHR+NTHR-1 of the dense, XOR-swizzled pixel-major tile described in conv_epilogue_fast.
 template <int BM, int NTHR>
-__device__ __forceinline__ void issue_residual_pieces(const ConvP& kp, int cm0, int pn0, uint32_t stage, int tid, int u0, int u1) {
+__device__ __forceinline__ void issue_residual_pieces(const ConvP& kp, int cm0, const TileMap& tm, uint32_t stage, int tid, int u0, int u1) {
   constexpr int CPR = BM / 8;
-  const char* resb = kp.residual + ((size_t)pn0 * kp.cout + cm0) * 2;
+  const char* resb = kp.residual + (size_t)cm0 * 2;
   const size_t rstride = (size_t)kp.cout * 2;
   const uint32_t wave_dst = __builtin_amdgcn_readfirstlane(stage + (tid >> 6) * 1024);
   for (int u = u0; u < u1; ++u) {
     const int slot = u * NTHR + tid, row = slot / CPR, c = slot - row * CPR;
-    glds16(resb + row * rstride + ((c ^ (row & 7)) << 4), wave_dst + u * (NTHR * 16));
+    glds16(resb + (size_t)tm.pix(row) * rstride + ((c ^ (row & 7)) << 4), wave_dst + u * (NTHR * 16));
   }
 }
 
@@ -189,7 +203,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 // vector), which in-kernel stamps put at 9k cycles per block -- as long as 4 K steps -- before the first byte is stored.
 // Arithmetic and its order are the generic path's: ((acc + bias) + bias_nc + residual) * out_scale, rounded once.
 template <typename T, int MT, int NT, int BM, int BN, bool RES, bool BNC, bool STATS, int NTHR>
-__device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&acc)[MT][NT], int cm0, int pn0, int wm, int wn, int lrow,
+__device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&acc)[MT][NT], int cm0, const TileMap& tm, int wm, int wn, int lrow,
                                                    int lq, char* smem_ring, bool bias_in_acc, int stage_off, int early_u0,
                                                    int early_u1) {
   char* smem = smem_ring + stage_off;                    // staged tile: placed so that the early residual pieces fit the free buffer
@@ -211,8 +225,8 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
     // already issued during the last K step into the ring buffer that step did not read (and are complete: that step's
     // vmcnt(0) + barrier covered them); only the rest is fetched here.
     const uint32_t stage = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    issue_residual_pieces<BM, NTHR>(kp, cm0, pn0, stage, tid, 0, early_u0);
-    issue_residual_pieces<BM, NTHR>(kp, cm0, pn0, stage, tid, early_u1, ITERS);
+    issue_residual_pieces<BM, NTHR>(kp, cm0, tm, stage, tid, 0, early_u0);
+    issue_residual_pieces<BM, NTHR>(kp, cm0, tm, stage, tid, early_u1, ITERS);
   }
   float4 bv[MT];
 #pragma unroll
@@ -228,12 +242,12 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
     const int hw = kp.hout * kp.wout;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const int pp = pn0 + prow0 + nt * 16;
+      const int pp = tm.pix(prow0 + nt * 16);
       np[nt] = bnc + (size_t)(kp.hw_shift >= 0 ? pp >> kp.hw_shift : pp / hw) * kp.ld_bias_nc + cm0 + col0;
     }
   }
   constexpr bool want_stats = STATS && NT == 4;
-  float* sp = want_stats ? kp.stats + ((size_t)((pn0 + wn * 64) >> 6) * p_cout + cm0 + col0) * 2 : nullptr;
+  float* sp = want_stats ? kp.stats + ((size_t)tm.strip(wn) * p_cout + cm0 + col0) * 2 : nullptr;
   // this lane's slot of (mt, nt): row prow0 + 16 nt, chunk (col0 / 8 + 2 mt) ^ (lrow & 7), half lq & 1
   char* sw = smem + prow0 * ROWB + (lq & 1) * 8;
   int coff[MT];
@@ -301,12 +315,12 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
   __syncthreads();
   // copy-out: 16 bytes per lane, whole rows; (row, chunk slot) advance incrementally (NTHR threads = DR rows + DC chunks)
   int row = tid / CPR, c = tid - row * CPR;
-  char* outb = kp.out + ((size_t)pn0 * p_cout + cm0) * 2;
+  char* outb = kp.out + (size_t)cm0 * 2;
   typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int u = 0; u < ITERS; ++u) {
     const u32x4_nt v_ = *reinterpret_cast<const u32x4_nt*>(smem + row * ROWB + c * 16);
-    __builtin_nontemporal_store(v_, reinterpret_cast<u32x4_nt*>(outb + row * rstride + ((c ^ (row & 7)) << 4)));
+    __builtin_nontemporal_store(v_, reinterpret_cast<u32x4_nt*>(outb + (size_t)tm.pix(row) * rstride + ((c ^ (row & 7)) << 4)));
     row += DR; c += DC;
     if (c >= CPR) { c -= CPR; ++row; }
   }
@@ -314,7 +328,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
 
 // ---- epilogue of one (cout tile, pixel tile[, K split]): lane holds couts co..co+3 of pixel pp for each (mt, nt)
 template <typename T, int MT, int NT, int BM, int BN, int NTHR = 256>
-__device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT][NT], int cm0, int pn0, int split, int wm, int wn,
+__device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT][NT], int cm0, const TileMap& tm, int split, int wm, int wn,
                                               int lrow, int lq, char* smem, bool bias_in_acc, int stage_off, int early_u0, int early_u1) {
   const int p_P = kp.P, p_cout = kp.cout, p_hout = kp.hout, p_wout = kp.wout;
   // ---- epilogue: lane holds couts co..co+3 of pixel pp for each (mt, nt): one 4-element vector load/store
@@ -322,7 +336,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
     float* part = kp.partial + (size_t)split * p_P * p_cout;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const int pp = pn0 + wn * 16 * NT + nt * 16 + lrow;
+      const int pp = tm.pix(wn * 16 * NT + nt * 16 + lrow);
       if (pp >= p_P) continue;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -334,9 +348,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
     return;
   }
   if constexpr (sizeof(T) == 2) {
-    if (pn0 + BN <= p_P) {                             // block-uniform
+    if (tm.pn0 + BN <= p_P) {                          // block-uniform
       const bool r_ = kp.residual != nullptr, b_ = kp.bias_nc != nullptr, s_ = NT == 4 && kp.stats != nullptr;
-#define DTS_EPI(R_, B_, S_) conv_epilogue_fast<T, MT, NT, BM, BN, R_, B_, S_, NTHR>(kp, acc, cm0, pn0, wm, wn, lrow, lq, smem, bias_in_acc, stage_off, early_u0, early_u1)
+#define DTS_EPI(R_, B_, S_) conv_epilogue_fast<T, MT, NT, BM, BN, R_, B_, S_, NTHR>(kp, acc, cm0, tm, wm, wn, lrow, lq, smem, bias_in_acc, stage_off, early_u0, early_u1)
       if (r_) { if (b_) { if (s_) DTS_EPI(true, true, true); else DTS_EPI(true, true, false); }
                 else    { if (s_) DTS_EPI(true, false, true); else DTS_EPI(true, false, false); } }
       else    { if (b_) { if (s_) DTS_EPI(false, true, true); else DTS_EPI(false, true, false); }
@@ -355,7 +369,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
   int ppv[NT], nsv[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int pp = pn0 + wn * 16 * NT + nt * 16 + lrow;
+    const int pp = tm.pix(wn * 16 * NT + nt * 16 + lrow);
     ppv[nt] = pp < p_P ? pp : -1;
     nsv[nt] = pp < p_P ? pp / hw : 0;
   }
@@ -381,9 +395,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
   // stores 16 contiguous bytes and a wave-instruction covers 1 KiB of whole output rows.
   constexpr bool VIA_LDS = sizeof(T) == 2;
   constexpr int ROWP = BM * 2 + 16;                    // LDS row pitch of the staged tile (pixel-major), bytes
-  static_assert(!VIA_LDS || BN * ROWP <= (NTHR == 256 ? 2 * (BM + BN) * 128 : (5 * 96 + 3 * BN) * 128), "staged tile must fit the ring");
+  static_assert(!VIA_LDS || BN * ROWP <= (NTHR == 256 ? 2 * (BM + BN) * 128 : (5 * 96 + 4 * 200) * 128), "staged tile must fit the ring");
   const bool want_stats = NT == 4 && kp.stats != nullptr;
-  float* sp = want_stats ? kp.stats + ((size_t)((pn0 + wn * 64) >> 6) * p_cout) * 2 : nullptr;
+  float* sp = want_stats ? kp.stats + ((size_t)tm.strip(wn) * p_cout) * 2 : nullptr;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int co = cm0 + wm * 16 * MT + mt * 16 + lq * 4;
@@ -434,7 +448,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) { ss4[r] += __shfl_xor(ss4[r], o, 64); sq4[r] += __shfl_xor(sq4[r], o, 64); }
       }
-      if (lrow == 0 && pn0 + wn * 64 < p_P) {
+      if (lrow == 0 && tm.pix(wn * 64) < p_P) {
         float4* d = reinterpret_cast<float4*>(sp + (size_t)co * 2);
         d[0] = make_float4(ss4[0], sq4[0], ss4[1], sq4[1]);
         d[1] = make_float4(ss4[2], sq4[2], ss4[3], sq4[3]);
@@ -444,14 +458,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
   if constexpr (VIA_LDS) {
     __syncthreads();
     constexpr int CPR = BM / 8;                          // 16-byte chunks per staged row
-    char* outb = kp.out + ((size_t)pn0 * p_cout + cm0) * 2;
-    const int rows = min(BN, p_P - pn0);
+    char* outb = kp.out + (size_t)cm0 * 2;
+    const int rows = min(BN, p_P - tm.pn0);
 #pragma unroll 4
     for (int t = threadIdx.x; t < rows * CPR; t += NTHR) {
       const int row = t / CPR, c = t - row * CPR;
       typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
       const u32x4_nt v_ = *reinterpret_cast<const u32x4_nt*>(smem + row * ROWP + c * 16);
-      __builtin_nontemporal_store(v_, reinterpret_cast<u32x4_nt*>(outb + (size_t)row * p_cout * 2 + c * 16));
+      __builtin_nontemporal_store(v_, reinterpret_cast<u32x4_nt*>(outb + (size_t)tm.pix(row) * p_cout * 2 + c * 16));
     }
   }
 }
@@ -629,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
       const int free_lo = (buf ^ 1) * STAGE_BYTES - stage_off;                 // free buffer in staged-tile coordinates
       early_u0 = max(0, (free_lo + PIECE - 1) / PIECE);
       early_u1 = min(PIECES, (free_lo + STAGE_BYTES) / PIECE);
-      issue_residual_pieces<BM, 64 * NW>(kp, cm0, pn0, lds_base + stage_off, tid, early_u0, early_u1);
+      issue_residual_pieces<BM, 64 * NW>(kp, cm0, linear_tile(pn0), lds_base + stage_off, tid, early_u0, early_u1);
     }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -656,52 +670,58 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
     buf ^= 1;
   }
 
-  conv_epilogue<T, MT, NT, BM, BN>(kp, acc, cm0, pn0, (int)blockIdx.y, wm, wn, lrow, lq, smem, bias_in_acc, stage_off, early_u0, early_u1);
+  conv_epilogue<T, MT, NT, BM, BN>(kp, acc, cm0, linear_tile(pn0), (int)blockIdx.y, wm, wn, lrow, lq, smem, bias_in_acc, stage_off, early_u0, early_u1);
 }
 #undef SET_ROWS
 #undef ISSUE_TILE
 #undef ADVANCE_K
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// Ping-pong variant (16-bit types, cout % 192 == 0): ONE 8-wave block per CU on a 192 x 256 (couts x pixels) tile.
+// Ping-pong + halo-tile variant (16-bit types, cout % 192 == 0, square power-of-two images >= 8, no fused upsample):
+// ONE 8-wave block per CU on a 192-cout x 256-pixel tile.  Two ideas, each answering a measurement (profiles/r02_conv_variants.txt):
 //
-// Why: in conv_igemm_kernel every wave runs [fragment reads -> 10 LDS-DMA issues -> 48 MFMAs -> vmcnt(0) + barrier] as one serial
-// chain of ~2.1k cycles per K step, and the two co-resident blocks of a CU move in lockstep (profiles/r01_conv_variants.txt), so the
-// matrix pipe idles while both waves of a SIMD read and issue loads (73 % MFMA-busy inside the K loop).  Here the two waves of a SIMD
-// are put in ANTI-PHASE by construction: waves 0-3 (group 0) and waves 4-7 (group 1; wave w and w+4 share a SIMD) alternate between a
-// LOAD segment (fragment reads of K tile t, LDS-DMA issue for later tiles) and a COMPUTE segment (the 48 MFMAs of tile t), group 1 one
-// segment behind group 0, with one workgroup barrier per segment: while one wave of a SIMD issues MFMAs its partner reads LDS and
-// issues DMA (MI355X_MICROARCH.md, "Two waves per SIMD": matrix beside memory is the complementary pairing).  The tile is twice as
-// wide in pixels, so a K step moves 7 LDS-DMA pieces per wave instead of 10 (the weight rows are shared by 256 pixels).
+// (1) ANTI-PHASE WAVE GROUPS.  In conv_igemm_kernel every wave runs [fragment reads -> 10 LDS-DMA issues -> 48 MFMAs -> vmcnt(0) +
+//     barrier] as one serial chain of ~2.1k cycles per K step and the two co-resident blocks of a CU move in lockstep, so the matrix
+//     pipe idles while both waves of a SIMD read and issue loads (73 % MFMA-busy inside the K loop).  Here waves 0-3 (group 0) and
+//     waves 4-7 (group 1; wave w and w+4 share a SIMD) alternate between a LOAD segment (fragment reads of K tile t, LDS-DMA issue)
+//     and a COMPUTE segment (the 48 MFMAs of tile t), group 1 one segment behind group 0, one workgroup barrier per segment: while
+//     one wave of a SIMD issues MFMAs its partner reads LDS and issues DMA (MI355X_MICROARCH.md, "Two waves per SIMD").
+// (2) HALO TILES.  Timing-only builds of the first ping-pong version showed the L2 -> LDS fill as the limit, not its latency and not
+//     its instruction count: with the activation pieces out of range (issued, written to LDS as zeros, nothing fetched) the loop ran
+//     20-25 % faster, with the weight pieces out of range 14 %, and neither a longer prefetch distance nor cheaper addressing nor an
+//     L2-friendly K order changed that.  A 3x3 conv staged as 9 shifted copies of the activation tile moves every activation byte
+//     nine times from L2 into LDS.  Here K runs channel chunk OUTER, tap INNER, and per 64-channel chunk each wave group stages the
+//     HALO of its 128 pixels once -- (8+2) x (16+2) = 180 rows of 128 bytes for an 8 x 16 pixel patch (2 x (10 x 10) rows for two
+//     8 x 8 images) -- and the nine taps read their B fragments from it at shifted rows: 1.4-1.6x one tile instead of 9x.  The fill
+//     per K tile drops from 56 KB to ~30 KB (24 KB of it weights).
 //
-// Work split: wave = (group g, index i): couts wm*96.. (wm = i & 1), pixels wn*64.. (wn = 2g + (i >> 1)).  Group g therefore reads
-// only pixel half g of the activation tile: the B halves are PRIVATE to a group; the weight tile A is read by both groups.
-// LDS-DMA distance (timing-only builds, profiles/r02_conv_variants.txt: without DMA the loop runs 18 % faster, and a DMA waited for one
-// segment after its issue is what set the pace): activation rows come from beyond the XCD's L2 (a CU's 3x3 halo of a 256-pixel tile
-// is 0.1-0.5 MB, 32 CUs share 4 MB), weight rows are L2 hits.  So
-//   * B_g: 3 stages x 16 KB per group; B_g(t+2) is issued in LOAD(t) into the stage of B_g(t-1) (last read in LOAD(t-1) by the same
-//     group) and is first read in LOAD(t+2): four segments of flight;
-//   * A rows 0-95 (filled by group 0): 2 stages x 12 KB; A0(t+1) is issued in group 0's LOAD(t) (segment 2t) into the stage of
-//     A0(t-1), last read by group 1 in segment 2t-1, complete before the barrier ending segment 2t+1, first read in segment 2t+2;
-//   * A rows 96-191 (filled by group 1): 3 stages x 12 KB; A1(t+2) is issued in group 1's LOAD(t) (segment 2t+1) into the stage of
-//     A1(t-1), last read in segment 2t-1, complete before the barrier ending segment 2t+2, first read in segment 2t+4.
-//   LDS: A0 2 x 12 KB | A1 3 x 12 KB | B 3 stages x 2 halves x 16 KB = 156 KB.
-// Waits: a wave's fragment reads are complete (lgkmcnt(0)) before the barrier that ends its LOAD segment; within a LOAD segment
-// the A pieces are issued BEFORE the B pieces, and the barrier that ends the following COMPUTE segment is preceded by vmcnt(4):
-// everything but the four youngest pieces -- B_g(t+2) -- has landed, i.e. B_g(t+1) and the A pieces just issued.
-// Accumulation order over K is that of conv_igemm_kernel (tap-major, 64 channels per step, two 32-deep MFMAs): bit-identical outputs.
-// DBG != 0: timing-only diagnostic builds (outputs wrong by construction; tools/conv_bench.py conv_variant=11/21/31):
-//   1 = no LDS-DMA after the prologue, 2 = no MFMAs, 3 = no fragment reads, 4 = every B piece out of range (zeros: the instruction
-//   issues and writes LDS but fetches nothing), 5 = every A piece out of range
-template <typename T, int DBG = 0>
+// Work split: wave = (group g, index i): couts wm*96.. (wm = i & 1), pixels (2g + (i >> 1))*64...  Group g owns pixel rows 128g.. of the
+// tile = an 8 x 16 half of the 16 x 16 patch (W >= 16; at W = 16 the patch is the image and the tile is linear) or two 8 x 8 images
+// (W = 8, tile = 4 consecutive images, linear).  Halo tiles are private to a group; the weight tile A is read by both groups.
+//   LDS: A rows 0-95: 2 stages x 12 KB (filled by group 0, one tile ahead) | A rows 96-191: 3 stages x 12 KB (group 1, two tiles ahead)
+//        | halo 2 buffers x 2 groups x 200 rows x 128 B = 100 KB      (160 KB in all)
+// Ordering (group 0: LOAD(t) = segment 2t, COMPUTE(t) = 2t+1; group 1 one later):
+//   * fragment reads complete (lgkmcnt(0)) before the barrier that ends a LOAD segment;
+//   * A0(t+1) is issued in group 0's LOAD(t) into the slot of A0(t-1) (last read in segment 2t-1), A1(t+2) in group 1's LOAD(t) into
+//     the slot of A1(t-1); both are complete before the barrier that ends the issuing wave's COMPUTE(t) (first reads: 2t+2 / 2t+4);
+//   * the halo of chunk c+1 goes into the buffer chunk c-1 used, one 8-row piece per wave per LOAD segment during chunk c (all of them
+//     in the one LOAD of a 1x1 conv), each AFTER that segment's A pieces: the COMPUTE-end wait is vmcnt(1) when a halo piece was
+//     issued in this LOAD and the next tile stays in the chunk, vmcnt(0) otherwise -- so a chunk's halo is complete before its
+//     first LOAD.  Padding: halo rows outside the image get an out-of-range lane offset, which the buffer load turns into zeros.
+// The summation order over K differs from conv_igemm_kernel's (same terms, other f32 rounding order); it is fixed, so identical
+// inputs still give identical outputs (ties stay ties).
+// DBG != 0: timing-only diagnostic builds (outputs wrong by construction; tools/conv_bench.py conv_variant=11/21/41/51):
+//   1 = no LDS-DMA after the prologue, 2 = no MFMAs, 4 = every halo piece out of range, 5 = every A piece out of range
+template <typename T, int TAPS, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
   constexpr int MT = 6, NT = 4, BM = 192, BN = 256, NTHR = 512;
   constexpr int BKE = 64, ES = 2;
-  constexpr int A_HALF = 96 * 128, B_HALF = 128 * 128, A1_OFF = 2 * A_HALF, B_OFF = 5 * A_HALF;     // see the LDS map above
+  constexpr int A_HALF = 96 * 128, A1_OFF = 2 * A_HALF, H_OFF = 5 * A_HALF, H_BUF = 200 * 128;       // see the LDS map above
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const char* const p_x1 = kp.x1; const char* const p_x2 = kp.x2; const char* const p_w = kp.w;
-  const int p_c1 = kp.c1, p_c2 = kp.c2, p_cin = kp.cin, p_win = kp.win, p_hout = kp.hout, p_wout = kp.wout;
-  const int p_taps = kp.taps, p_up = kp.up, p_P = kp.P, p_n_ct = kp.n_ct, p_n_pt = kp.n_pt;
+  const int p_c1 = kp.c1, p_c2 = kp.c2, p_cin = kp.cin, W = kp.win, H = kp.hin;
+  constexpr int p_taps = TAPS;                           // 9 (3x3) or 1 (1x1): the tap loop is unrolled
+  const int p_n_ct = kp.n_ct, p_n_pt = kp.n_pt;
 
   const int nblk = p_n_ct * p_n_pt;
   int bid = blockIdx.x;
@@ -710,7 +730,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
   }
   const int ct = bid % p_n_ct, pt = bid / p_n_ct;
-  const int cm0 = ct * BM, pn0 = pt * BN;
+  const int cm0 = ct * BM;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -718,6 +738,30 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
   const int wm = wi & 1, wn = 2 * grp + (wi >> 1);
   const int chunk = lane & 7, r0 = lane >> 3;
   const int lrow = lane & 15, lq = lane >> 4;
+
+  // ---- tile geometry (uniform).  W >= 32: 16 x 16 patch of one image; W <= 16: 256 consecutive pixels (one 16 x 16 image / four 8 x 8)
+  const int hw = H * W;
+  TileMap tm;
+  tm.pn0 = pt * BN; tm.w = W;
+  int img0, y0 = 0, x0 = 0;                              // first image of the tile, patch origin
+  if (W >= 32) {
+    const int tpr = W >> 4, tpi = tpr * (H >> 4);        // patches per row / per image (powers of two)
+    const int tin = pt & (tpi - 1);
+    img0 = pt / tpi;
+    y0 = (tin / tpr) << 4; x0 = (tin & (tpr - 1)) << 4;
+    tm.patch = 1; tm.porg = img0 * hw + y0 * W + x0;
+    tm.strip0 = img0 * (hw >> 6) + tin * 4;
+  } else {
+    img0 = tm.pn0 / hw;
+    tm.patch = 0; tm.porg = 0; tm.strip0 = tm.pn0 >> 6;
+  }
+  const int bd = (p_taps == 9) ? 1 : 0;                  // halo border
+  const int sw = W >= 16 ? 16 : 8;                       // segment width; a group's 128 pixels = nseg segments of 8 x sw pixels
+  const int hwid = sw + 2 * bd;                          // halo row length in pixels
+  const int seg_rows = (8 + 2 * bd) * hwid;              // halo rows per segment: 180 / 100 (3x3), 128 / 64 (1x1)
+  const int nseg = 16 / sw;                              // 1 or 2
+  const int hr_total = nseg * seg_rows;                  // <= 200
+  const int npieces = (hr_total + 7) >> 3;               // 8-row LDS-DMA pieces per group halo: 23 / 25 / 16
 
   const int K = p_taps * p_cin;
   const int nk_all = p_taps * (p_cin / BKE);
@@ -728,93 +772,63 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
   const int schunk = (chunk ^ (r0 & 7)) * 16;
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
-  // ---- this lane's rows: A share = rows grp*96 + 8*(wi + 4j) + r0 (j < 3), B share = rows 8*(wi + 4j) + r0 of half grp (j < 4).
-  // Addresses are (descriptor, 32-bit lane offset, scalar offset).
-  //
-  // K ORDER: channel chunk outer, tap inner (k tile kt = chunk * taps + tap).  conv_igemm_kernel walks K tap-major, so the 9 taps that
-  // re-read (nearly) the same 64-channel slice of the same pixel rows are a whole cin sweep apart -- hundreds of KB per CU, 32 CUs per
-  // 4 MB L2 -- and every one of the 9 reads came from beyond L2 (timing-only builds: with the activation pieces out of range the loop
-  // ran 25 % faster, with the weight pieces out of range 16 %; profiles/r02_conv_variants.txt).  Tap-inner order makes 8 of the 9
-  // reads L2 hits.  With it the tap is a UNIFORM byte delta (dh*win + dw) * cs * ES on top of a per-lane base that never changes:
-  // it lives in the scalar offset (the descriptor base is moved back by one row + one pixel so that the deltas are non-negative),
-  // and the image border is a 9-bit validity mask per row: an invalid (padding) row gets an out-of-range lane offset = zeros.
-  // Weights are stored [cout][tap][cin]: the A tile of (chunk, tap) is at byte (tap*cin + chunk*64) * ES of each row.
-  // The summation order over K therefore differs from conv_igemm_kernel's (same terms, different f32 rounding order); it is fixed,
-  // so identical inputs still give identical outputs.  The fused nearest-2x upsample is not a uniform delta: those layers stay on
-  // conv_igemm_kernel (launcher).
-  const int hw_in = kp.hin * p_win;
-  const uint32_t sh1 = (uint32_t)(p_win + 1) * p_c1 * ES, sh2 = (uint32_t)(p_win + 1) * p_c2 * ES;
+  // ---- LDS-DMA addressing: (descriptor, 32-bit lane offset, scalar offset).  A share = rows grp*96 + 8*(wi + 4j) + r0 (j < 3) of the
+  // weight tile; weights are stored [cout][tap][cin]: the A tile of (chunk, tap) is at byte (tap*cin + chunk*64) * ES of each row.
   const dts_i32x4 rs_w = make_rsrc(p_w, (uint32_t)((size_t)kp.cout * K * ES));
-  const dts_i32x4 rs_x1 = make_rsrc(p_x1 - sh1, (uint32_t)((size_t)kp.n * hw_in * p_c1 * ES) + sh1);
-  const dts_i32x4 rs_x2 = make_rsrc(p_x2 ? p_x2 - sh2 : p_x1, p_x2 ? (uint32_t)((size_t)kp.n * hw_in * p_c2 * ES) + sh2 : 0u);
   uint32_t avo[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) avo[j] = DBG == 5 ? DTS_OOR : (uint32_t)((cm0 + grp * 96 + 8 * (wi + 4 * j) + r0) * K) * ES + schunk;
-  const uint32_t a_dst = lds_base + grp * A1_OFF + (8 * wi) * 128;               // + j*32*128 + stage*A_HALF (group g fills ring g)
-  const uint32_t b_dst = lds_base + B_OFF + grp * B_HALF + (8 * wi) * 128;       // + j*32*128 + stage*2*B_HALF
+  const uint32_t a_dst = lds_base + grp * A1_OFF + (8 * wi) * 128;               // + j*32*128 + slot*A_HALF (group g fills ring g)
+  const uint32_t h_dst = lds_base + H_OFF + grp * H_BUF + (8 * wi) * 128;        // + j*32*128 + buffer*2*H_BUF
 
-  int pixoff[4];                                       // source pixel index n*hin*win + h*win + w of the row's centre tap (-1: no pixel)
-  uint32_t vmask[4];                                   // bit t: tap t of this row is inside the image
+  // halo rows of this lane: piece wi + 4j (j < 7), row 8*(wi + 4j) + r0 -> source pixel (or -1: padding / beyond the halo)
+  int hpix[7];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int pp = pn0 + grp * 128 + 8 * (wi + 4 * j) + r0;
-    pixoff[j] = -1; vmask[j] = 0;
-    if (pp < p_P) {
-      int n, ho, wo;
-      if (kp.hw_shift >= 0) {
-        n = pp >> kp.hw_shift;
-        const int rem = pp & ((1 << kp.hw_shift) - 1);
-        ho = rem >> kp.w_shift; wo = rem & ((1 << kp.w_shift) - 1);
-      } else {
-        const int hw = p_hout * p_wout;
-        n = pp / hw;
-        const int rem = pp - n * hw;
-        ho = rem / p_wout; wo = rem - ho * p_wout;
-      }
-      pixoff[j] = n * hw_in + ho * p_win + wo;
-      if (p_taps == 9) {
-#pragma unroll
-        for (int t9 = 0; t9 < 9; ++t9) {
-          const int hu = ho + t9 / 3 - 1, wu = wo + t9 % 3 - 1;
-          if ((unsigned)hu < (unsigned)p_hout && (unsigned)wu < (unsigned)p_wout) vmask[j] |= 1u << t9;
-        }
-      } else {
-        vmask[j] = 1u;
-      }
+  for (int j = 0; j < 7; ++j) {
+    const int hr = 8 * (wi + 4 * j) + r0;
+    hpix[j] = -1;
+    if (hr < hr_total) {
+      int sg, q;
+      if (nseg == 2 && hr >= seg_rows) { sg = 1; q = hr - seg_rows; } else { sg = 0; q = hr; }
+      int hy, hx;
+      if (hwid == 18) { hy = q / 18; hx = q - hy * 18; }
+      else if (hwid == 16) { hy = q >> 4; hx = q & 15; }
+      else if (hwid == 10) { hy = q / 10; hx = q - hy * 10; }
+      else { hy = q >> 3; hx = q & 7; }
+      int img, y, x;
+      if (sw == 16) { img = img0; y = y0 + grp * 8 + hy - bd; x = x0 + hx - bd; }
+      else { img = img0 + grp * 2 + sg; y = hy - bd; x = hx - bd; }
+      if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && img < kp.n) hpix[j] = (img * H + y) * W + x;
     }
   }
-  uint32_t bvo[4];                                     // centre-tap lane offsets of the B rows in the current source
-  // K position of the NEXT B tile to issue, in (chunk, tap) order
-  int kt_b = ks_begin;
-  int tap = kt_b % p_taps, ci0 = (kt_b / p_taps) * BKE;
-  bool b_src2 = ci0 >= p_c1;
-#define PP_SET_SRC()                                                                                          \
+  uint32_t hvo[7];                                     // lane offsets of the halo rows in the current source
+  dts_i32x4 rs_x;                                      // descriptor of the current source (x1, or x2 past the concat boundary)
+#define PP_SET_SRC(ci0_)                                                                                      \
   {                                                                                                           \
-    b_src2 = ci0 >= p_c1;                                                                                     \
-    const int cs_ = b_src2 ? p_c2 : p_c1;                                                                     \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                             \
-      bvo[j] = (pixoff[j] >= 0 && DBG != 4) ? (uint32_t)(pixoff[j] * cs_) * ES + schunk : DTS_OOR;            \
+    const bool s2_ = (ci0_) >= p_c1;                                                                          \
+    const int cs_ = s2_ ? p_c2 : p_c1;                                                                        \
+    rs_x = make_rsrc(s2_ ? p_x2 : p_x1, (uint32_t)((size_t)kp.n * hw * cs_ * ES));                            \
+    _Pragma("unroll") for (int j = 0; j < 7; ++j)                                                             \
+      hvo[j] = (hpix[j] >= 0 && DBG != 4) ? (uint32_t)(hpix[j] * cs_) * ES + schunk : DTS_OOR;                \
   }
-#define PP_ISSUE_B(stage_)                                                                                    \
-  {                                                                                                           \
-    const uint32_t d_ = b_dst + (stage_) * (2 * B_HALF);                                                      \
-    const int cs_ = b_src2 ? p_c2 : p_c1;                                                                     \
-    const int dlt_ = (p_taps == 9) ? ((tap / 3) * p_win + tap % 3) : (p_win + 1);      /* (dh+1)*win + (dw+1) */ \
-    const uint32_t so_ = (uint32_t)(dlt_ * cs_ + (b_src2 ? ci0 - p_c1 : ci0)) * ES;                           \
-    const uint32_t bit_ = 1u << tap;                                                                          \
-    if (b_src2) { _Pragma("unroll") for (int j = 0; j < 4; ++j) bdma16((vmask[j] & bit_) ? bvo[j] : DTS_OOR, rs_x2, so_, d_ + j * (32 * 128)); } \
-    else        { _Pragma("unroll") for (int j = 0; j < 4; ++j) bdma16((vmask[j] & bit_) ? bvo[j] : DTS_OOR, rs_x1, so_, d_ + j * (32 * 128)); } \
-    if (++tap == p_taps) { tap = 0; ci0 += BKE; if (ci0 == p_c1) PP_SET_SRC(); }                              \
-  }
-  int a_tap = ks_begin % p_taps, a_ci0 = (ks_begin / p_taps) * BKE;       // K position of the NEXT A tile this wave issues
-  int a_stage = 0;                                                         // its ring slot (2 slots for group 0, 3 for group 1)
+  int a_so = ((ks_begin % p_taps) * p_cin + (ks_begin / p_taps) * BKE) * ES;     // scalar offset of the NEXT A tile this wave issues
+  int a_tap = ks_begin % p_taps;
+  int a_slot = 0;                                                                 // its ring slot (2 slots for group 0, 3 for group 1)
 #define PP_ISSUE_A()     /* this group's 96 rows of the next A tile */                                         \
   {                                                                                                           \
-    const uint32_t d_ = a_dst + a_stage * A_HALF;                                                             \
-    const uint32_t so_ = (uint32_t)(a_tap * p_cin + a_ci0) * ES;                                              \
-    _Pragma("unroll") for (int j = 0; j < 3; ++j) bdma16(avo[j], rs_w, so_, d_ + j * (32 * 128));             \
-    if (++a_tap == p_taps) { a_tap = 0; a_ci0 += BKE; }                                                       \
-    if (++a_stage == (grp ? 3 : 2)) a_stage = 0;                                                              \
+    const uint32_t d_ = a_dst + a_slot * A_HALF;                                                              \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) bdma16(avo[j], rs_w, (uint32_t)a_so, d_ + j * (32 * 128));  \
+    if (++a_tap == p_taps) { a_tap = 0; a_so += (BKE - (p_taps - 1) * p_cin) * ES; } else a_so += p_cin * ES; \
+    if (++a_slot == (grp ? 3 : 2)) a_slot = 0;                                                                \
+  }
+
+  // ---- B fragments come from the halo tile: centre row of this lane's pixel for each n tile; a tap adds a uniform row delta
+  int hc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int pl = (wn & 1) * 64 + nt * 16 + lrow;     // pixel within the group's 128
+    if (sw == 16) hc[nt] = ((pl >> 4) + bd) * hwid + (pl & 15) + bd;
+    else hc[nt] = (pl >> 6) * seg_rows + (((pl >> 3) & 7) + bd) * hwid + (pl & 7) + bd;
   }
 
   const bool bias_in_acc = kp.splits == 1 && kp.bias != nullptr;
@@ -827,77 +841,118 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{b0.x, b0.y, b0.z, b0.w};
   }
 
-  // ---- prologue: group 0: A0(0); group 1: A1(0), A1(1); both: B_g(0), B_g(1)
+  // ---- prologue: group 0: A0(0); group 1: A1(0), A1(1); both: the halo of the first chunk (all pieces).  The launcher makes every
+  // K split a whole number of chunks (nk % TAPS == 0, ks_begin % TAPS == 0).
+  int ci0 = (ks_begin / p_taps) * BKE;                   // channel offset of the chunk being computed
+  const int nchunks = nk / p_taps;
   PP_ISSUE_A();
   if (grp == 1 && nk > 1) PP_ISSUE_A();
-  PP_SET_SRC();
-  PP_ISSUE_B(0);
-  if (nk > 1) PP_ISSUE_B(1);
+  PP_SET_SRC(ci0);
+  {
+    const uint32_t so_ = (uint32_t)(ci0 >= p_c1 ? ci0 - p_c1 : ci0) * ES;
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+      if (wi + 4 * j < npieces) bdma16(hvo[j], rs_x, so_, h_dst + j * (32 * 128));
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_barrier" ::: "memory");
   if (grp == 1) asm volatile("s_barrier" ::: "memory");          // the stagger: group 1 runs one segment behind group 0
 
-  for (int t = 0; t < nk; ++t) {
-    // ---------------- LOAD(t): fragments of tile t -> registers; DMA: this group's A rows (one / two tiles ahead), then B_g(t+2)
-    const char* sa = smem + (wm ? A1_OFF + (t % 3) * A_HALF : (t & 1) * A_HALF);
-    const char* sb = smem + B_OFF + ((t % 3) * 2 + grp) * B_HALF + ((wn & 1) * 64) * 128;
-    uint4 fa[MT], fb[NT], ga[MT], gb[NT];
-    if constexpr (DBG == 3) {
+  int t = 0;                                             // K tile index inside this block's range
+  uint32_t a0_rd = 0, a1_rd = 0;                         // read slots of the A rings (byte offsets)
+  uint32_t h_rd = H_OFF + grp * H_BUF;                   // halo buffer being read (byte offset); the other one is h_rd ^ toggles below
+  for (int c = 0; c < nchunks; ++c) {
+    const bool more = c + 1 < nchunks;
+    const int next_ci0 = ci0 + BKE;
+    const uint32_t h_wr = (h_rd == H_OFF + grp * H_BUF) ? h_dst + 2 * H_BUF : h_dst;       // LDS-DMA destination: the other buffer
+    uint32_t h_so = 0;
+    if (more) {
+      // the next chunk's halo goes out during this chunk; all of this chunk's pieces were issued during the previous one, so the
+      // source may be switched now
+      if ((next_ci0 >= p_c1) != (ci0 >= p_c1)) PP_SET_SRC(next_ci0);
+      h_so = (uint32_t)(next_ci0 >= p_c1 ? next_ci0 - p_c1 : next_ci0) * ES;
+    }
+#pragma unroll 1
+    for (int tap = 0; tap < p_taps; ++tap) {
+      // ---------------- LOAD(t): fragments of tile t -> registers; DMA: this group's A rows, then (at most) its halo piece(s)
+      const char* sa = smem + (wm ? A1_OFF + a1_rd : a0_rd);
+      const char* sh = smem + h_rd;
+      // (the tap loop is NOT unrolled: unrolled, hipcc hoists the 9 x 4 fragment addresses and spills -- 256 VGPRs + scratch)
+      const int dh3 = (tap * 11) >> 5;                   // tap / 3 for tap < 9
+      const int dlt = (p_taps == 9) ? (dh3 - 1) * hwid + (tap - 3 * dh3 - 1) : 0;
+      uint4 fa[MT], fb[NT], ga[MT], gb[NT];
 #pragma unroll
-      for (int i = 0; i < NT; ++i) { fb[i] = make_uint4(t, i, 1, 2); gb[i] = make_uint4(i, t, 3, 4); }
-#pragma unroll
-      for (int i = 0; i < MT; ++i) { fa[i] = make_uint4(t, i, 5, 6); ga[i] = make_uint4(i, t, 7, 8); }
-    } else {
-#pragma unroll
-      for (int i = 0; i < NT; ++i) fb[i] = *reinterpret_cast<const uint4*>(sb + swz(i * 16 + lrow, lq));
+      for (int i = 0; i < NT; ++i) {
+        const int row = hc[i] + dlt;
+        const int off = row * 128 + ((lq ^ (row & 7)) << 4);
+        fb[i] = *reinterpret_cast<const uint4*>(sh + off);
+        gb[i] = *reinterpret_cast<const uint4*>(sh + (off ^ 64));              // chunk lq + 4: slot index with bit 2 flipped
+      }
 #pragma unroll
       for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq));
 #pragma unroll
-      for (int i = 0; i < NT; ++i) gb[i] = *reinterpret_cast<const uint4*>(sb + swz(i * 16 + lrow, lq + 4));
-#pragma unroll
       for (int i = 0; i < MT; ++i) ga[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq + 4));
+      bool flying = false;                               // a halo piece was issued after this LOAD's A pieces
+      if constexpr (DBG != 1) {
+        if (t + 1 + grp < nk) PP_ISSUE_A();                    // group 0: A0(t+1); group 1: A1(t+2)
+        if (more) {
+          if constexpr (p_taps == 9) {
+            if (tap < 7) {
+              // piece `tap` of the next halo: the lane offsets rotate through hvo[0] (7 rotations = identity by the chunk's end)
+              if (wi + 4 * tap < npieces) { bdma16(hvo[0], rs_x, h_so, h_wr + tap * (32 * 128)); flying = true; }
+              const uint32_t h0 = hvo[0];
+#pragma unroll
+              for (int j = 0; j < 6; ++j) hvo[j] = hvo[j + 1];
+              hvo[6] = h0;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bdma16(hvo[j], rs_x, h_so, h_wr + j * (32 * 128));
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every fragment is in registers: slots / buffers may be refilled
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- COMPUTE(t)
+      __builtin_amdgcn_s_setprio(1);
+      if constexpr (DBG == 2) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(fa[i].x), "v"(ga[i].w));
+#pragma unroll
+        for (int i = 0; i < NT; ++i) asm volatile("" ::"v"(fb[i].x), "v"(gb[i].w));
+      } else {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], ga[i], gb[j]);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      // the A pieces issued in LOAD(t) have landed; the halo piece issued after them may fly on (the chunk's last tiles issue none,
+      // so the whole halo is in before the next chunk's first LOAD)
+      if (p_taps == 9 && tap < 7 && flying) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      ++t;
+      a0_rd ^= A_HALF;
+      a1_rd = (a1_rd == 2 * A_HALF) ? 0 : a1_rd + A_HALF;
     }
-    const bool more_b = t + 2 < nk;
-    if constexpr (DBG != 1) {
-      if (t + 1 + grp < nk) PP_ISSUE_A();                      // group 0: A0(t+1); group 1: A1(t+2)
-      if (more_b) PP_ISSUE_B((t + 2) % 3);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // every fragment is in registers: the stages may be refilled
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    // ---------------- COMPUTE(t)
-    __builtin_amdgcn_s_setprio(1);
-    if constexpr (DBG == 2) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(fa[i].x), "v"(ga[i].w));
-#pragma unroll
-      for (int i = 0; i < NT; ++i) asm volatile("" ::"v"(fb[i].x), "v"(gb[i].w));
-    } else {
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], ga[i], gb[j]);
-    }
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    // all but the four youngest pieces (B_g(t+2), issued last in LOAD(t)) have landed: B_g(t+1) and this group's A pieces
-    if (more_b && DBG != 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
+    ci0 = next_ci0;
+    h_rd = (h_rd == H_OFF + grp * H_BUF) ? H_OFF + (2 + grp) * H_BUF : H_OFF + grp * H_BUF;
   }
   if (grp == 0) asm volatile("s_barrier" ::: "memory");          // matches group 1's last COMPUTE barrier
 #undef PP_SET_SRC
-#undef PP_ISSUE_B
 #undef PP_ISSUE_A
   __syncthreads();
 
-  conv_epilogue<T, MT, NT, BM, BN, NTHR>(kp, acc, cm0, pn0, (int)blockIdx.y, wm, wn, lrow, lq, smem, bias_in_acc, 0, 0, 0);
+  conv_epilogue<T, MT, NT, BM, BN, NTHR>(kp, acc, cm0, tm, (int)blockIdx.y, wm, wn, lrow, lq, smem, bias_in_acc, 0, 0, 0);
 }
 
 // split-K second pass: fixed-order sum of the f32 slabs + the conv epilogue
@@ -1057,7 +1112,7 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, C
 }
 
 // ---- ping-pong launcher: one block per (192-cout tile, 256-pixel tile[, K split]); 512 threads, 136 KB of LDS
-template <typename T, int DBG = 0>
+template <typename T, int TAPS, int DBG = 0>
 int launch_conv_pp(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, ConvCall& call) {
   if constexpr (sizeof(T) != 2) {
     return DTS_ERR_UNSUPPORTED;
@@ -1075,27 +1130,32 @@ int launch_conv_pp(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes
       else if (nblk < 192) splits = (256 + nblk - 1) / nblk;     // one resident block per CU: fill 256 slots
       if (splits > 8) splits = 8;
       if (splits > nk / 8) splits = nk / 8;
+      if (splits > nk / TAPS) splits = nk / TAPS;
       while (splits > 1 && (long long)splits * p.P * p.cout * 4 > ws_bytes) --splits;
       if (splits < 1) splits = 1;
     }
-    q.ks_per_split = (nk + splits - 1) / splits;
-    splits = (nk + q.ks_per_split - 1) / q.ks_per_split;
+    {   // every split a whole number of channel chunks (TAPS tiles each)
+      const int nchunk = nk / TAPS;
+      const int cps = (nchunk + splits - 1) / splits;
+      q.ks_per_split = cps * TAPS;
+      splits = (nchunk + cps - 1) / cps;
+    }
     q.splits = splits;
     q.partial = ws;
     float* const stats_req = p.stats;
     const bool stats_in_reduce = splits > 1 && stats_req != nullptr && (p.hout * p.wout) % 64 == 0 && p.cout % 4 == 0;
     if (splits > 1) q.stats = nullptr;
     call.stats_written = q.stats != nullptr || stats_in_reduce;
-    constexpr size_t lds = (size_t)(5 * 96 + 3 * BN) * 128;       // A0 2 x 96 rows, A1 3 x 96 rows, B 3 x 256 rows of 128 bytes
+    constexpr size_t lds = (size_t)(5 * 96 + 4 * 200) * 128;      // A0 2 x 96 rows, A1 3 x 96 rows, halo 2 buffers x 2 groups x 200 rows
     static bool attr_done = false;
     if (!attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<T, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<T, TAPS, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_done = true;
     }
     if (call.ev_start != nullptr && call.ev_stop != nullptr)
-      hipExtLaunchKernelGGL((conv_pp_kernel<T, DBG>), dim3(nblk, splits), dim3(512), lds, st, call.ev_start, call.ev_stop, 0, q);
+      hipExtLaunchKernelGGL((conv_pp_kernel<T, TAPS, DBG>), dim3(nblk, splits), dim3(512), lds, st, call.ev_start, call.ev_stop, 0, q);
     else
-      hipLaunchKernelGGL((conv_pp_kernel<T, DBG>), dim3(nblk, splits), dim3(512), lds, st, q);
+      hipLaunchKernelGGL((conv_pp_kernel<T, TAPS, DBG>), dim3(nblk, splits), dim3(512), lds, st, q);
     DTS_CHECK_LAUNCH("dts_conv2d(ping-pong)");
     if (splits > 1 && stats_in_reduce) {
       q.stats = stats_req;
@@ -1128,17 +1188,20 @@ int conv_dispatch(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes,
   if (std::is_same<T, float>::value && tile == 192) tile = (p.cout % 128 == 0) ? 128 : 64;
   // DTS_CONV_VARIANT: 1 = the 8-wave ping-pong kernel wherever it applies (16-bit, cout % 192 == 0), 0 = never, unset = by shape
   const int variant = dts_knob_get(DTS_KNOB_CONV_VARIANT);
-  const bool pp_ok = !p.up && (long long)p.n * p.hin * p.win * (p.c1 > p.c2 ? p.c1 : p.c2) * 2 < (1ll << 31) - (1 << 20) &&
-                     (long long)p.cout * p.taps * p.cin * 2 < (1ll << 31);      // 32-bit lane offsets; uniform tap deltas
+  // ping-pong / halo kernel: square power-of-two images of 8..., whole 256-pixel tiles, 32-bit lane offsets, no fused upsample
+  const bool pp_ok = !p.up && p.hin == p.win && p.win >= 8 && (p.win & (p.win - 1)) == 0 && p.P % 256 == 0 &&
+                     (long long)p.n * p.hin * p.win * (p.c1 > p.c2 ? p.c1 : p.c2) * 2 < (1ll << 31) &&
+                     (long long)p.cout * p.taps * p.cin * 2 < (1ll << 31);
   if (!std::is_same<T, float>::value && p.cout % 192 == 0 && g_tile_override <= 0 && pp_ok) {
     const long long blocks_pp = (long long)(p.cout / 192) * ((p.P + 255) / 256);
     const bool auto_pp = false;                                   // (set from measurements: tools/conv_bench.py --variants)
-    if (variant == 1 || (variant < 0 && auto_pp && blocks_pp >= 256)) return launch_conv_pp<T>(p, st, ws, ws_bytes, call);
-    if (variant == 11) return launch_conv_pp<T, 1>(p, st, ws, ws_bytes, call);     // timing-only diagnostics
-    if (variant == 21) return launch_conv_pp<T, 2>(p, st, ws, ws_bytes, call);
-    if (variant == 31) return launch_conv_pp<T, 3>(p, st, ws, ws_bytes, call);
-    if (variant == 41) return launch_conv_pp<T, 4>(p, st, ws, ws_bytes, call);
-    if (variant == 51) return launch_conv_pp<T, 5>(p, st, ws, ws_bytes, call);
+#define DTS_PP(DBG_) (p.taps == 9 ? launch_conv_pp<T, 9, DBG_>(p, st, ws, ws_bytes, call) : launch_conv_pp<T, 1, DBG_>(p, st, ws, ws_bytes, call))
+    if (variant == 1 || (variant < 0 && auto_pp && blocks_pp >= 256)) return DTS_PP(0);
+    if (variant == 11) return DTS_PP(1);     // timing-only diagnostics
+    if (variant == 21) return DTS_PP(2);
+    if (variant == 41) return DTS_PP(4);
+    if (variant == 51) return DTS_PP(5);
+#undef DTS_PP
   }
   if (g_tile_override > 0 && p.cout % g_tile_override == 0) tile = g_tile_override;
   // fragment prefetch pays on the long K loops of the 3x3 layers; f32 (parity mode) keeps the lean order: its 192-cout
