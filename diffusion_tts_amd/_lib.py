@@ -29,6 +29,7 @@ class ConvArgs(C.Structure):
 SIGNATURES = {
     'dts_nchw_to_nhwc': [_p, _p, _i, _i, _i, _i, _i, _p],
     'dts_nhwc_to_nchw': [_p, _i, _p, _i, _i, _i, _i, _p],
+    'dts_nchw_to_nhwc_pad': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
     'dts_pack_conv_weight': [_p, _p, _i, _i, _i, _i, _i, _p, _p],
     'dts_conv2d': [C.POINTER(ConvArgs), _p],
     'dts_conv_in3': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
@@ -62,7 +63,7 @@ SIGNATURES = {
 OTHER = {'dts_version': ([], _i), 'dts_set_tuning': ([_i, _i], _i), 'dts_get_tuning': ([_i], _i), 'dts_last_error': ([], C.c_char_p), 'dts_gn_ws_floats': ([_i, _i], _i64)}
 
 _lib = None
-ABI_VERSION = 103              # include/dts.h DTS_ABI_VERSION this binding was written against (ConvArgs = 160 bytes)
+ABI_VERSION = 104              # include/dts.h DTS_ABI_VERSION this binding was written against (ConvArgs = 160 bytes)
 
 
 def load():

@@ -59,12 +59,19 @@ __device__ __forceinline__ void att_block(const AttP& p, int& nh, int& qb) {
 // 16-bit element types
 // QT = query tiles (of 16) per wave: a block covers 64*QT queries.  QT = 2 halves the K/V staging, the barriers and the K / V^T
 // fragment reads per query (each fragment feeds both query tiles); used for long sequences, where the grid stays large.
-template <typename T, int D, int QT>
+// DV < D (head dim 512, the SD VAE's single-head mid-block attention): a block produces only DV of the D output channels (value
+// slice vs = slot % (D/DV)): the 128 accumulator registers a 512-wide output would need do not fit beside the 64 of the query
+// fragments.  Q.K^T is recomputed per slice (1.5x the FLOPs of the unsplit product); the K/V tiles then go to LDS without the
+// register prefetch (PREF = false: 96 more registers).
+template <typename T, int D, int QT, int DV = D, bool PREF = true>
 __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
-  constexpr int ES = 2, ROWB = D * ES + 32;        // LDS row stride in bytes
-  constexpr int CH = D / 8;                        // 16-byte chunks per row
+  constexpr int ES = 2, ROWB = D * ES + 32;        // LDS row stride of K in bytes
+  constexpr int VROWB = DV * ES + 32;              // LDS row stride of the V slice
+  constexpr int CH = D / 8;                        // 16-byte chunks per K row
+  constexpr int CHV = DV / 8;                      // ... per V-slice row
   constexpr int KSTEPS = D / 32;                   // MFMA k-steps for Q.K
-  constexpr int DT = D / 16;                       // output d tiles
+  constexpr int DT = DV / 16;                      // output d tiles
+  constexpr int NSL = D / DV;                      // value slices
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sK = smem;
   char* sV = smem + 64 * ROWB;
@@ -72,6 +79,8 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
   const int lq = lane & 15, lg = lane >> 4;
   int nh, qblk;
   att_block(p, nh, qblk);
+  int vs = 0;
+  if constexpr (NSL > 1) { vs = nh % NSL; nh /= NSL; }
   const int n = nh / p.heads, head = nh - n * p.heads;
   const int C = p.heads * D;
   const size_t rowstride = (size_t)3 * C * ES;
@@ -101,31 +110,73 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
   }
 
   const int ntiles = (p.t + 63) / 64;
-  constexpr int NCH = (64 * CH) / 256;             // 16-byte chunks of K (and of V) staged per thread per tile
-  uint4 pk[NCH], pv[NCH];
+  constexpr int NCH = (64 * CH) / 256;             // 16-byte chunks of K staged per thread per tile
+  constexpr int NCHV = (64 * CHV) / 256;           // ... of the V slice
+  constexpr int NPF = PREF ? NCH : 1, NPFV = PREF ? NCHV : 1;
+  uint4 pk[NPF], pv[NPFV];
+  const char* const vbase = base + (size_t)2 * C * ES + (size_t)vs * DV * ES;
   // register prefetch: the next tile's K/V rows are in flight while the current tile feeds the MFMAs
 #define ATT_LOAD_TILE(key0_)                                                                     \
   _Pragma("unroll") for (int u = 0; u < NCH; ++u) {                                               \
     const int idx = tid + 256 * u, r = idx / CH, c = idx - r * CH;                                \
-    pk[u] = make_uint4(0, 0, 0, 0); pv[u] = make_uint4(0, 0, 0, 0);                               \
-    if ((key0_) + r < p.t) {                                                                      \
-      const char* g = base + (size_t)((key0_) + r) * rowstride + c * 16;                          \
-      pk[u] = *reinterpret_cast<const uint4*>(g + (size_t)C * ES);                                \
-      pv[u] = *reinterpret_cast<const uint4*>(g + (size_t)2 * C * ES);                            \
-    }                                                                                             \
+    pk[u] = make_uint4(0, 0, 0, 0);                                                               \
+    if ((key0_) + r < p.t) pk[u] = *reinterpret_cast<const uint4*>(base + (size_t)((key0_) + r) * rowstride + c * 16 + (size_t)C * ES); \
+  }                                                                                               \
+  _Pragma("unroll") for (int u = 0; u < NCHV; ++u) {                                              \
+    const int idx = tid + 256 * u, r = idx / CHV, c = idx - r * CHV;                              \
+    pv[u] = make_uint4(0, 0, 0, 0);                                                               \
+    if ((key0_) + r < p.t) pv[u] = *reinterpret_cast<const uint4*>(vbase + (size_t)((key0_) + r) * rowstride + c * 16); \
   }
-  ATT_LOAD_TILE(0);
+  if constexpr (PREF) { ATT_LOAD_TILE(0); }
   for (int kt = 0; kt < ntiles; ++kt) {
     const int key0 = kt * 64;
     __syncthreads();                                 // previous tile fully consumed
+    if constexpr (PREF) {
 #pragma unroll
-    for (int u = 0; u < NCH; ++u) {
-      const int idx = tid + 256 * u, r = idx / CH, c = idx - r * CH;
-      *reinterpret_cast<uint4*>(sK + r * ROWB + c * 16) = pk[u];
-      *reinterpret_cast<uint4*>(sV + r * ROWB + c * 16) = pv[u];
+      for (int u = 0; u < NCH; ++u) {
+        const int idx = tid + 256 * u, r = idx / CH, c = idx - r * CH;
+        *reinterpret_cast<uint4*>(sK + r * ROWB + c * 16) = pk[u];
+      }
+#pragma unroll
+      for (int u = 0; u < NCHV; ++u) {
+        const int idx = tid + 256 * u, r = idx / CHV, c = idx - r * CHV;
+        *reinterpret_cast<uint4*>(sV + r * VROWB + c * 16) = pv[u];
+      }
+    } else {
+      // no register prefetch: global -> LDS in groups of four chunks (the loads of a group are in flight together)
+#pragma unroll
+      for (int u0 = 0; u0 < NCH; u0 += 4) {
+        uint4 tk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = tid + 256 * (u0 + u), r = idx / CH, c = idx - r * CH;
+          tk[u] = make_uint4(0, 0, 0, 0);
+          if (key0 + r < p.t) tk[u] = *reinterpret_cast<const uint4*>(base + (size_t)(key0 + r) * rowstride + c * 16 + (size_t)C * ES);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = tid + 256 * (u0 + u), r = idx / CH, c = idx - r * CH;
+          *reinterpret_cast<uint4*>(sK + r * ROWB + c * 16) = tk[u];
+        }
+      }
+#pragma unroll
+      for (int u0 = 0; u0 < NCHV; u0 += 4) {
+        uint4 tv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = tid + 256 * (u0 + u), r = idx / CHV, c = idx - r * CHV;
+          tv[u] = make_uint4(0, 0, 0, 0);
+          if (key0 + r < p.t) tv[u] = *reinterpret_cast<const uint4*>(vbase + (size_t)(key0 + r) * rowstride + c * 16);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = tid + 256 * (u0 + u), r = idx / CHV, c = idx - r * CHV;
+          *reinterpret_cast<uint4*>(sV + r * VROWB + c * 16) = tv[u];
+        }
+      }
     }
     __syncthreads();
-    if (kt + 1 < ntiles) { ATT_LOAD_TILE(key0 + 64); }
+    if constexpr (PREF) { if (kt + 1 < ntiles) { ATT_LOAD_TILE(key0 + 64); } }
 
     // ---- S^T tiles: 4 x (16 keys x 16 queries) per query tile; a K fragment feeds every query tile
     f32x4_t sacc[QT][4];
@@ -193,8 +244,8 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
     for (int kk = 0; kk < 2; ++kk) {
       // transposed read: lane 4q'+p' of each 16-lane group addresses row q', columns 4p'..4p'+3 of a 4x16 block
       const int rq = (lane & 15) >> 2, rp = lane & 3;
-      const char* va = sV + (32 * kk + 4 * lg + rq) * ROWB + rp * 8;
-      const char* vb = va + 16 * ROWB;
+      const char* va = sV + (32 * kk + 4 * lg + rq) * VROWB + rp * 8;
+      const char* vb = va + 16 * VROWB;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(va + dt * 32));
@@ -213,7 +264,7 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
     const int qrow = q0 + qt * 16 + lq;
     if (qrow < p.t) {
       const float inv = 1.f / l_run[qt];
-      T* orow = reinterpret_cast<T*>(p.out) + ((size_t)n * p.t + qrow) * C + head * D;
+      T* orow = reinterpret_cast<T*>(p.out) + ((size_t)n * p.t + qrow) * C + head * D + vs * DV;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -335,7 +386,7 @@ __global__ __launch_bounds__(256) void attention32_kernel(const AttP p) {
 }
 
 template <typename K>
-int launch_att(K kernel, const AttP& p0, size_t lds, hipStream_t st, int qblock = 64) {
+int launch_att(K kernel, const AttP& p0, size_t lds, hipStream_t st, int qblock = 64, int slices = 1) {
   {   // hipFuncSetAttribute once per kernel (every instantiation has the same pointer TYPE, so the key is the pointer itself)
     static std::mutex mu;
     static std::unordered_map<const void*, size_t> done;
@@ -349,7 +400,7 @@ int launch_att(K kernel, const AttP& p0, size_t lds, hipStream_t st, int qblock 
   AttP p = p0;
   p.qblocks = (p.t + qblock - 1) / qblock;
   p.xcd_remap = dts_knob_get(DTS_KNOB_ATT_XCD) != 0;        // DTS_ATT_XCD=0 restores the plain block order (A/B aid)
-  const long long nblk = (long long)p.qblocks * p.n * p.heads;
+  const long long nblk = (long long)p.qblocks * p.n * p.heads * slices;
   DTS_CHECK_ARG(nblk < (1ll << 31), "dts_attention: grid too large");
   hipLaunchKernelGGL(kernel, dim3((unsigned)nblk), dim3(256), lds, st, p);
   DTS_CHECK_LAUNCH("dts_attention");
@@ -368,6 +419,8 @@ int att16(const AttP& p, hipStream_t st) {
       return launch_att(attention16_kernel<T, 64, 1>, p, lds, st);
     case 128: return launch_att(attention16_kernel<T, 128, 1>, p, lds, st);
     case 256: return launch_att(attention16_kernel<T, 256, 1>, p, lds, st);
+    case 512:   // two 256-wide value slices per (sample, head, query block); K rows 1056 B + V-slice rows 544 B per key
+      return launch_att(attention16_kernel<T, 512, 1, 256, false>, p, (size_t)64 * (512 * 2 + 32) + (size_t)64 * (256 * 2 + 32), st, 64, 2);
   }
   return DTS_ERR_UNSUPPORTED;
 }
@@ -387,7 +440,8 @@ int att32(const AttP& p, hipStream_t st) {
 extern "C" int dts_attention(const void* qkv, void* out, int dtype, int n, int t, int heads, int d, float scale, dts_stream s) {
   DTS_CHECK_ARG(qkv && out, "dts_attention: null pointer");
   DTS_CHECK_ARG(n > 0 && t > 0 && heads > 0, "dts_attention: bad shape");
-  DTS_CHECK_ARG(d == 64 || d == 128 || d == 256, "dts_attention: head dim %d unsupported (64/128/256)", d);
+  DTS_CHECK_ARG(d == 64 || d == 128 || d == 256 || (d == 512 && dtype != DTS_F32),
+                "dts_attention: head dim %d unsupported (64/128/256; 512 in the 16-bit types)", d);
   AttP p{(const char*)qkv, (char*)out, n, t, heads, d, scale * 1.4426950408889634f, 0, 1};
   hipStream_t st = to_stream(s);
   switch (dtype) {

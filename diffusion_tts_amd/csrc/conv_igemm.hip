@@ -395,7 +395,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
   // stores 16 contiguous bytes and a wave-instruction covers 1 KiB of whole output rows.
   constexpr bool VIA_LDS = sizeof(T) == 2;
   constexpr int ROWP = BM * 2 + 16;                    // LDS row pitch of the staged tile (pixel-major), bytes
-  static_assert(!VIA_LDS || BN * ROWP <= (NTHR == 256 ? 2 * (BM + BN) * 128 : (5 * 96 + 4 * 200) * 128), "staged tile must fit the ring");
+  static_assert(!VIA_LDS || BN * ROWP <= (NTHR == 256 ? 2 * (BM + BN) * 128 : (6 * 96 + 2 * 328) * 128), "staged tile must fit the ring");
   const bool want_stats = NT == 4 && kp.stats != nullptr;
   float* sp = want_stats ? kp.stats + ((size_t)tm.strip(wn) * p_cout) * 2 : nullptr;
 #pragma unroll
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
 #undef ADVANCE_K
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// Ping-pong + halo-tile variant (16-bit types, cout % 192 == 0, square power-of-two images >= 8, no fused upsample):
+// Ping-pong + halo-tile variant (16-bit types, cout % 192 == 0, square power-of-two images >= 16, no fused upsample):
 // ONE 8-wave block per CU on a 192-cout x 256-pixel tile.  Two ideas, each answering a measurement (profiles/r02_conv_variants.txt):
 //
 // (1) ANTI-PHASE WAVE GROUPS.  In conv_igemm_kernel every wave runs [fragment reads -> 10 LDS-DMA issues -> 48 MFMAs -> vmcnt(0) +
@@ -690,24 +690,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
 //     its instruction count: with the activation pieces out of range (issued, written to LDS as zeros, nothing fetched) the loop ran
 //     20-25 % faster, with the weight pieces out of range 14 %, and neither a longer prefetch distance nor cheaper addressing nor an
 //     L2-friendly K order changed that.  A 3x3 conv staged as 9 shifted copies of the activation tile moves every activation byte
-//     nine times from L2 into LDS.  Here K runs channel chunk OUTER, tap INNER, and per 64-channel chunk each wave group stages the
-//     HALO of its 128 pixels once -- (8+2) x (16+2) = 180 rows of 128 bytes for an 8 x 16 pixel patch (2 x (10 x 10) rows for two
-//     8 x 8 images) -- and the nine taps read their B fragments from it at shifted rows: 1.4-1.6x one tile instead of 9x.  The fill
-//     per K tile drops from 56 KB to ~30 KB (24 KB of it weights).
+//     nine times from L2 into LDS.  Here K runs channel chunk OUTER, tap INNER, and per 64-channel chunk the block stages the HALO of
+//     its 16 x 16 pixel patch once -- 18 x 18 = 324 rows of 128 bytes -- and the nine taps read their B fragments from it at shifted
+//     rows: 1.27x one tile instead of 9x.  The fill per K tile drops from 56 KB to ~29 KB (24 KB of it weights).
 //
-// Work split: wave = (group g, index i): couts wm*96.. (wm = i & 1), pixels (2g + (i >> 1))*64...  Group g owns pixel rows 128g.. of the
-// tile = an 8 x 16 half of the 16 x 16 patch (W >= 16; at W = 16 the patch is the image and the tile is linear) or two 8 x 8 images
-// (W = 8, tile = 4 consecutive images, linear).  Halo tiles are private to a group; the weight tile A is read by both groups.
-//   LDS: A rows 0-95: 2 stages x 12 KB (filled by group 0, one tile ahead) | A rows 96-191: 3 stages x 12 KB (group 1, two tiles ahead)
-//        | halo 2 buffers x 2 groups x 200 rows x 128 B = 100 KB      (160 KB in all)
+// Work split: wave = (group g, index i): couts g*96.., pixels i*64.. of the 16 x 16 patch (the image itself at W = 16).  The weight
+// halves are therefore PRIVATE to a group (each group stages its own 96 rows, 3 slots, two tiles ahead = 3-4 segments of flight);
+// the halo tile (18 x 18 = 324 rows of 128 bytes for a 3x3 conv, the 256 pixel rows themselves for a 1x1) is shared by the two
+// groups and double-buffered per chunk.  [An earlier arrangement -- groups split by pixel half, private halos, shared weights --
+// left group 0's weight rows one segment of flight and ran 13 % below its own no-weight-fetch build.]
+//   LDS: A 2 groups x 3 slots x 12 KB = 72 KB | halo 2 buffers x 328 rows x 128 B = 82 KB      (154 KB)
 // Ordering (group 0: LOAD(t) = segment 2t, COMPUTE(t) = 2t+1; group 1 one later):
 //   * fragment reads complete (lgkmcnt(0)) before the barrier that ends a LOAD segment;
-//   * A0(t+1) is issued in group 0's LOAD(t) into the slot of A0(t-1) (last read in segment 2t-1), A1(t+2) in group 1's LOAD(t) into
-//     the slot of A1(t-1); both are complete before the barrier that ends the issuing wave's COMPUTE(t) (first reads: 2t+2 / 2t+4);
-//   * the halo of chunk c+1 goes into the buffer chunk c-1 used, one 8-row piece per wave per LOAD segment during chunk c (all of them
-//     in the one LOAD of a 1x1 conv), each AFTER that segment's A pieces: the COMPUTE-end wait is vmcnt(1) when a halo piece was
-//     issued in this LOAD and the next tile stays in the chunk, vmcnt(0) otherwise -- so a chunk's halo is complete before its
-//     first LOAD.  Padding: halo rows outside the image get an out-of-range lane offset, which the buffer load turns into zeros.
+//   * A_g(t+2) is issued in LOAD(t) into the slot of A_g(t-1), last read in LOAD(t-1) by the same group; first read in LOAD(t+2);
+//   * the halo of chunk c+1 goes into the buffer chunk c-1 used (last read: group 1's last LOAD of chunk c-1, one segment before
+//     group 0's first LOAD of chunk c, where the first piece is issued): one 8-row piece per wave per LOAD segment for the first six
+//     tiles of chunk c (all four in the one LOAD of a 1x1 conv);
+//   * COMPUTE(t) ends with a counted wait that leaves only the pieces issued in LOAD(t) in flight (vmcnt(3 + #halo pieces)): A_g(t+1)
+//     and every older halo piece have landed; a 3x3 chunk issues no halo piece in its last three tiles, so the next chunk's halo is
+//     complete two tiles before its first LOAD; a 1x1 chunk is one tile, so there the wait is vmcnt(0).
+// Padding: halo rows outside the image get an out-of-range lane offset, which the buffer load turns into zeros.
 // The summation order over K differs from conv_igemm_kernel's (same terms, other f32 rounding order); it is fixed, so identical
 // inputs still give identical outputs (ties stay ties).
 // DBG != 0: timing-only diagnostic builds (outputs wrong by construction; tools/conv_bench.py conv_variant=11/21/41/51):
@@ -716,7 +718,7 @@ template <typename T, int TAPS, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
   constexpr int MT = 6, NT = 4, BM = 192, BN = 256, NTHR = 512;
   constexpr int BKE = 64, ES = 2;
-  constexpr int A_HALF = 96 * 128, A1_OFF = 2 * A_HALF, H_OFF = 5 * A_HALF, H_BUF = 200 * 128;       // see the LDS map above
+  constexpr int A_HALF = 96 * 128, A_RING = 3 * A_HALF, H_OFF = 2 * A_RING, H_BUF = 328 * 128;       // see the LDS map above
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const char* const p_x1 = kp.x1; const char* const p_x2 = kp.x2; const char* const p_w = kp.w;
   const int p_c1 = kp.c1, p_c2 = kp.c2, p_cin = kp.cin, W = kp.win, H = kp.hin;
@@ -735,7 +737,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = w >> 2, wi = w & 3;
-  const int wm = wi & 1, wn = 2 * grp + (wi >> 1);
+  const int wm = grp, wn = wi;
   const int chunk = lane & 7, r0 = lane >> 3;
   const int lrow = lane & 15, lq = lane >> 4;
 
@@ -755,13 +757,11 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
     img0 = tm.pn0 / hw;
     tm.patch = 0; tm.porg = 0; tm.strip0 = tm.pn0 >> 6;
   }
-  const int bd = (p_taps == 9) ? 1 : 0;                  // halo border
-  const int sw = W >= 16 ? 16 : 8;                       // segment width; a group's 128 pixels = nseg segments of 8 x sw pixels
-  const int hwid = sw + 2 * bd;                          // halo row length in pixels
-  const int seg_rows = (8 + 2 * bd) * hwid;              // halo rows per segment: 180 / 100 (3x3), 128 / 64 (1x1)
-  const int nseg = 16 / sw;                              // 1 or 2
-  const int hr_total = nseg * seg_rows;                  // <= 200
-  const int npieces = (hr_total + 7) >> 3;               // 8-row LDS-DMA pieces per group halo: 23 / 25 / 16
+  constexpr int bd = (p_taps == 9) ? 1 : 0;              // halo border
+  constexpr int hwid = 16 + 2 * bd;                      // halo row length in pixels: 18 / 16
+  constexpr int hr_total = hwid * hwid;                  // 324 / 256 halo rows
+  constexpr int npieces = (hr_total + 7) / 8;            // 41 / 32 LDS-DMA pieces of 8 rows, dealt round-robin to the 8 waves
+  constexpr int NHP = (npieces + 7) / 8;                 // pieces per wave: 6 / 4
 
   const int K = p_taps * p_cin;
   const int nk_all = p_taps * (p_cin / BKE);
@@ -778,57 +778,48 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
   uint32_t avo[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) avo[j] = DBG == 5 ? DTS_OOR : (uint32_t)((cm0 + grp * 96 + 8 * (wi + 4 * j) + r0) * K) * ES + schunk;
-  const uint32_t a_dst = lds_base + grp * A1_OFF + (8 * wi) * 128;               // + j*32*128 + slot*A_HALF (group g fills ring g)
-  const uint32_t h_dst = lds_base + H_OFF + grp * H_BUF + (8 * wi) * 128;        // + j*32*128 + buffer*2*H_BUF
+  const uint32_t a_dst = lds_base + grp * A_RING + (8 * wi) * 128;               // + j*32*128 + slot*A_HALF (private ring of group g)
+  const uint32_t h_dst = lds_base + H_OFF + (8 * w) * 128;                       // + j*64*128 + buffer*H_BUF  (piece w + 8j)
 
-  // halo rows of this lane: piece wi + 4j (j < 7), row 8*(wi + 4j) + r0 -> source pixel (or -1: padding / beyond the halo)
-  int hpix[7];
+  // halo rows of this lane: piece w + 8j (j < NHP), row 8*(w + 8j) + r0 -> source pixel (or -1: padding / beyond the halo)
+  int hpix[NHP];
 #pragma unroll
-  for (int j = 0; j < 7; ++j) {
-    const int hr = 8 * (wi + 4 * j) + r0;
+  for (int j = 0; j < NHP; ++j) {
+    const int hr = 8 * (w + 8 * j) + r0;
     hpix[j] = -1;
     if (hr < hr_total) {
-      int sg, q;
-      if (nseg == 2 && hr >= seg_rows) { sg = 1; q = hr - seg_rows; } else { sg = 0; q = hr; }
-      int hy, hx;
-      if (hwid == 18) { hy = q / 18; hx = q - hy * 18; }
-      else if (hwid == 16) { hy = q >> 4; hx = q & 15; }
-      else if (hwid == 10) { hy = q / 10; hx = q - hy * 10; }
-      else { hy = q >> 3; hx = q & 7; }
-      int img, y, x;
-      if (sw == 16) { img = img0; y = y0 + grp * 8 + hy - bd; x = x0 + hx - bd; }
-      else { img = img0 + grp * 2 + sg; y = hy - bd; x = hx - bd; }
-      if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && img < kp.n) hpix[j] = (img * H + y) * W + x;
+      const int hy = hr / hwid, hx = hr - hy * hwid;
+      const int y = y0 + hy - bd, x = x0 + hx - bd;
+      if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) hpix[j] = (img0 * H + y) * W + x;
     }
   }
-  uint32_t hvo[7];                                     // lane offsets of the halo rows in the current source
+  uint32_t hvo[NHP];                                   // lane offsets of the halo rows in the current source
   dts_i32x4 rs_x;                                      // descriptor of the current source (x1, or x2 past the concat boundary)
 #define PP_SET_SRC(ci0_)                                                                                      \
   {                                                                                                           \
     const bool s2_ = (ci0_) >= p_c1;                                                                          \
     const int cs_ = s2_ ? p_c2 : p_c1;                                                                        \
     rs_x = make_rsrc(s2_ ? p_x2 : p_x1, (uint32_t)((size_t)kp.n * hw * cs_ * ES));                            \
-    _Pragma("unroll") for (int j = 0; j < 7; ++j)                                                             \
+    _Pragma("unroll") for (int j = 0; j < NHP; ++j)                                                           \
       hvo[j] = (hpix[j] >= 0 && DBG != 4) ? (uint32_t)(hpix[j] * cs_) * ES + schunk : DTS_OOR;                \
   }
   int a_so = ((ks_begin % p_taps) * p_cin + (ks_begin / p_taps) * BKE) * ES;     // scalar offset of the NEXT A tile this wave issues
   int a_tap = ks_begin % p_taps;
-  int a_slot = 0;                                                                 // its ring slot (2 slots for group 0, 3 for group 1)
+  int a_slot = 0;                                                                 // its ring slot
 #define PP_ISSUE_A()     /* this group's 96 rows of the next A tile */                                         \
   {                                                                                                           \
     const uint32_t d_ = a_dst + a_slot * A_HALF;                                                              \
     _Pragma("unroll") for (int j = 0; j < 3; ++j) bdma16(avo[j], rs_w, (uint32_t)a_so, d_ + j * (32 * 128));  \
     if (++a_tap == p_taps) { a_tap = 0; a_so += (BKE - (p_taps - 1) * p_cin) * ES; } else a_so += p_cin * ES; \
-    if (++a_slot == (grp ? 3 : 2)) a_slot = 0;                                                                \
+    if (++a_slot == 3) a_slot = 0;                                                                            \
   }
 
   // ---- B fragments come from the halo tile: centre row of this lane's pixel for each n tile; a tap adds a uniform row delta
   int hc[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int pl = (wn & 1) * 64 + nt * 16 + lrow;     // pixel within the group's 128
-    if (sw == 16) hc[nt] = ((pl >> 4) + bd) * hwid + (pl & 15) + bd;
-    else hc[nt] = (pl >> 6) * seg_rows + (((pl >> 3) & 7) + bd) * hwid + (pl & 7) + bd;
+    const int pl = wn * 64 + nt * 16 + lrow;           // pixel of the patch: (pl >> 4, pl & 15)
+    hc[nt] = ((pl >> 4) + bd) * hwid + (pl & 15) + bd;
   }
 
   const bool bias_in_acc = kp.splits == 1 && kp.bias != nullptr;
@@ -841,30 +832,30 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{b0.x, b0.y, b0.z, b0.w};
   }
 
-  // ---- prologue: group 0: A0(0); group 1: A1(0), A1(1); both: the halo of the first chunk (all pieces).  The launcher makes every
-  // K split a whole number of chunks (nk % TAPS == 0, ks_begin % TAPS == 0).
+  // ---- prologue: A_g(0), A_g(1), the halo of the first chunk (all pieces).  The launcher makes every K split a whole number of
+  // chunks (nk % TAPS == 0, ks_begin % TAPS == 0).
   int ci0 = (ks_begin / p_taps) * BKE;                   // channel offset of the chunk being computed
   const int nchunks = nk / p_taps;
   PP_ISSUE_A();
-  if (grp == 1 && nk > 1) PP_ISSUE_A();
+  if (nk > 1) PP_ISSUE_A();
   PP_SET_SRC(ci0);
   {
     const uint32_t so_ = (uint32_t)(ci0 >= p_c1 ? ci0 - p_c1 : ci0) * ES;
 #pragma unroll
-    for (int j = 0; j < 7; ++j)
-      if (wi + 4 * j < npieces) bdma16(hvo[j], rs_x, so_, h_dst + j * (32 * 128));
+    for (int j = 0; j < NHP; ++j)
+      if (w + 8 * j < npieces) bdma16(hvo[j], rs_x, so_, h_dst + j * (64 * 128));
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asm volatile("s_barrier" ::: "memory");
   if (grp == 1) asm volatile("s_barrier" ::: "memory");          // the stagger: group 1 runs one segment behind group 0
 
   int t = 0;                                             // K tile index inside this block's range
-  uint32_t a0_rd = 0, a1_rd = 0;                         // read slots of the A rings (byte offsets)
-  uint32_t h_rd = H_OFF + grp * H_BUF;                   // halo buffer being read (byte offset); the other one is h_rd ^ toggles below
+  uint32_t a_rd = grp * A_RING;                          // read slot of this group's A ring (byte offset)
+  uint32_t h_rd = H_OFF;                                 // halo buffer being read (byte offset)
   for (int c = 0; c < nchunks; ++c) {
     const bool more = c + 1 < nchunks;
     const int next_ci0 = ci0 + BKE;
-    const uint32_t h_wr = (h_rd == H_OFF + grp * H_BUF) ? h_dst + 2 * H_BUF : h_dst;       // LDS-DMA destination: the other buffer
+    const uint32_t h_wr = (h_rd == H_OFF) ? h_dst + H_BUF : h_dst;                         // LDS-DMA destination: the other buffer
     uint32_t h_so = 0;
     if (more) {
       // the next chunk's halo goes out during this chunk; all of this chunk's pieces were issued during the previous one, so the
@@ -875,7 +866,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
 #pragma unroll 1
     for (int tap = 0; tap < p_taps; ++tap) {
       // ---------------- LOAD(t): fragments of tile t -> registers; DMA: this group's A rows, then (at most) its halo piece(s)
-      const char* sa = smem + (wm ? A1_OFF + a1_rd : a0_rd);
+      const char* sa = smem + a_rd;
       const char* sh = smem + h_rd;
       // (the tap loop is NOT unrolled: unrolled, hipcc hoists the 9 x 4 fragment addresses and spills -- 256 VGPRs + scratch)
       const int dh3 = (tap * 11) >> 5;                   // tap / 3 for tap < 9
@@ -892,22 +883,23 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
       for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq));
 #pragma unroll
       for (int i = 0; i < MT; ++i) ga[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq + 4));
-      bool flying = false;                               // a halo piece was issued after this LOAD's A pieces
+      int inflight = 0;                                  // pieces issued in this LOAD: they may still be flying when COMPUTE(t) ends
       if constexpr (DBG != 1) {
-        if (t + 1 + grp < nk) PP_ISSUE_A();                    // group 0: A0(t+1); group 1: A1(t+2)
+        if (t + 2 < nk) { PP_ISSUE_A(); inflight = 3; }        // A_g(t+2)
         if (more) {
           if constexpr (p_taps == 9) {
-            if (tap < 7) {
-              // piece `tap` of the next halo: the lane offsets rotate through hvo[0] (7 rotations = identity by the chunk's end)
-              if (wi + 4 * tap < npieces) { bdma16(hvo[0], rs_x, h_so, h_wr + tap * (32 * 128)); flying = true; }
+            if (tap < NHP) {
+              // piece `tap` of the next halo: the lane offsets rotate through hvo[0] (NHP rotations = identity by the chunk's end)
+              if (w + 8 * tap < npieces) { bdma16(hvo[0], rs_x, h_so, h_wr + tap * (64 * 128)); ++inflight; }
               const uint32_t h0 = hvo[0];
 #pragma unroll
-              for (int j = 0; j < 6; ++j) hvo[j] = hvo[j + 1];
-              hvo[6] = h0;
+              for (int j = 0; j < NHP - 1; ++j) hvo[j] = hvo[j + 1];
+              hvo[NHP - 1] = h0;
             }
           } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bdma16(hvo[j], rs_x, h_so, h_wr + j * (32 * 128));
+            for (int j = 0; j < NHP; ++j) bdma16(hvo[j], rs_x, h_so, h_wr + j * (64 * 128));
+            inflight = 0;                                      // a 1x1 chunk is one tile: everything must land before the next LOAD
           }
         }
       }
@@ -934,18 +926,18 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
       }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
-      // the A pieces issued in LOAD(t) have landed; the halo piece issued after them may fly on (the chunk's last tiles issue none,
-      // so the whole halo is in before the next chunk's first LOAD)
-      if (p_taps == 9 && tap < 7 && flying) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      // everything issued before LOAD(t) has landed -- A_g(t+1), the older halo pieces; only LOAD(t)'s own pieces may fly on
+      if (inflight == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (inflight == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if (inflight == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_barrier" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       ++t;
-      a0_rd ^= A_HALF;
-      a1_rd = (a1_rd == 2 * A_HALF) ? 0 : a1_rd + A_HALF;
+      a_rd = (a_rd == grp * A_RING + 2 * A_HALF) ? grp * A_RING : a_rd + A_HALF;
     }
     ci0 = next_ci0;
-    h_rd = (h_rd == H_OFF + grp * H_BUF) ? H_OFF + (2 + grp) * H_BUF : H_OFF + grp * H_BUF;
+    h_rd = (h_rd == H_OFF) ? H_OFF + H_BUF : H_OFF;
   }
   if (grp == 0) asm volatile("s_barrier" ::: "memory");          // matches group 1's last COMPUTE barrier
 #undef PP_SET_SRC
@@ -1146,7 +1138,7 @@ int launch_conv_pp(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes
     const bool stats_in_reduce = splits > 1 && stats_req != nullptr && (p.hout * p.wout) % 64 == 0 && p.cout % 4 == 0;
     if (splits > 1) q.stats = nullptr;
     call.stats_written = q.stats != nullptr || stats_in_reduce;
-    constexpr size_t lds = (size_t)(5 * 96 + 4 * 200) * 128;      // A0 2 x 96 rows, A1 3 x 96 rows, halo 2 buffers x 2 groups x 200 rows
+    constexpr size_t lds = (size_t)(6 * 96 + 2 * 328) * 128;      // A: 2 groups x 3 slots x 96 rows; halo: 2 buffers x 328 rows
     static bool attr_done = false;
     if (!attr_done) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<T, TAPS, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1188,15 +1180,19 @@ int conv_dispatch(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes,
   if (std::is_same<T, float>::value && tile == 192) tile = (p.cout % 128 == 0) ? 128 : 64;
   // DTS_CONV_VARIANT: 1 = the 8-wave ping-pong kernel wherever it applies (16-bit, cout % 192 == 0), 0 = never, unset = by shape
   const int variant = dts_knob_get(DTS_KNOB_CONV_VARIANT);
-  // ping-pong / halo kernel: square power-of-two images of 8..., whole 256-pixel tiles, 32-bit lane offsets, no fused upsample
-  const bool pp_ok = !p.up && p.hin == p.win && p.win >= 8 && (p.win & (p.win - 1)) == 0 && p.P % 256 == 0 &&
+  // ping-pong / halo kernel: square power-of-two images of 16..., whole 256-pixel tiles, 32-bit lane offsets, no fused upsample
+  const bool pp_ok = !p.up && p.hin == p.win && p.win >= 16 && (p.win & (p.win - 1)) == 0 && p.P % 256 == 0 &&
                      (long long)p.n * p.hin * p.win * (p.c1 > p.c2 ? p.c1 : p.c2) * 2 < (1ll << 31) &&
                      (long long)p.cout * p.taps * p.cin * 2 < (1ll << 31);
   if (!std::is_same<T, float>::value && p.cout % 192 == 0 && g_tile_override <= 0 && pp_ok) {
     const long long blocks_pp = (long long)(p.cout / 192) * ((p.P + 255) / 256);
-    const bool auto_pp = false;                                   // (set from measurements: tools/conv_bench.py --variants)
+    // measured (tools/conv_bench.py --variants, profiles/r02_conv_variants.txt): 3x3 layers +3..11 %, 1x1 layers -10..15 % (their
+    // 6-12 K tiles do not amortise the exposed prologue/epilogue of a one-block-per-CU kernel): 3x3 only
+    // with a residual input the epilogue's residual fetch is exposed here (no early fetch yet): short-K layers (K = 1728) then lose
+    // 2-3 % to conv_igemm_kernel, longer ones still gain
+    const bool auto_pp = p.taps == 9 && (p.residual == nullptr || p.cin >= 384);
 #define DTS_PP(DBG_) (p.taps == 9 ? launch_conv_pp<T, 9, DBG_>(p, st, ws, ws_bytes, call) : launch_conv_pp<T, 1, DBG_>(p, st, ws, ws_bytes, call))
-    if (variant == 1 || (variant < 0 && auto_pp && blocks_pp >= 256)) return DTS_PP(0);
+    if (variant == 1 || (variant < 0 && auto_pp && blocks_pp >= 64)) return DTS_PP(0);
     if (variant == 11) return DTS_PP(1);     // timing-only diagnostics
     if (variant == 21) return DTS_PP(2);
     if (variant == 41) return DTS_PP(4);

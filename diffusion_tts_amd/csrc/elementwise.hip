@@ -383,6 +383,27 @@ extern "C" int dts_nchw_to_nhwc(const float* src, void* dst, int dtype, int n, i
   });
   return DTS_OK;
 }
+// NCHW f32 [n][c][h][w] -> NHWC [n][h][w][cpad], channels c..cpad-1 zero (SD latents have 4 channels; the MFMA conv wants cin % 64 == 0)
+template <typename T>
+__global__ void nchw_to_nhwc_pad_kernel(const float* __restrict__ src, T* __restrict__ dst, int n, int c, int h, int w, int cpad) {
+  const long long total = (long long)n * h * w * cpad;
+  GSL(i, total) {
+    const int ch = (int)(i % cpad);
+    const long long pix = i / cpad;
+    const int x = (int)(pix % w), y = (int)((pix / w) % h), b = (int)(pix / ((long long)w * h));
+    st1<T>(dst + i, ch < c ? src[(((size_t)b * c + ch) * h + y) * w + x] : 0.f);
+  }
+}
+extern "C" int dts_nchw_to_nhwc_pad(const float* src, void* dst, int dtype, int n, int c, int h, int w, int cpad, dts_stream s) {
+  DTS_CHECK_ARG(src && dst && n > 0 && c > 0 && h > 0 && w > 0 && cpad >= c, "dts_nchw_to_nhwc_pad: bad args");
+  ST;
+  const long long total = (long long)n * cpad * h * w;
+  DTS_DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL((nchw_to_nhwc_pad_kernel<T>), dim3(grid1d(total)), dim3(256), 0, st, src, (T*)dst, n, c, h, w, cpad);
+    DTS_CHECK_LAUNCH("dts_nchw_to_nhwc_pad");
+  });
+  return DTS_OK;
+}
 extern "C" int dts_nhwc_to_nchw(const void* src, int dtype, float* dst, int n, int c, int h, int w, dts_stream s) {
   DTS_CHECK_ARG(src && dst && n > 0 && c > 0 && h > 0 && w > 0, "dts_nhwc_to_nchw: bad args");
   ST;

@@ -60,6 +60,14 @@ def nchw_to_nhwc(x, dtype):
     return out
 
 
+def nchw_to_nhwc_pad(x, dtype, cpad):
+    """f32 NCHW [n,c,h,w] -> NHWC [n,h,w,cpad] in `dtype`, channels c.. zero."""
+    n, c, h, w = x.shape
+    out = torch.empty((n, h, w, cpad), dtype=dtype, device=x.device)
+    _call('dts_nchw_to_nhwc_pad', _ptr(x, 'x', torch.float32), _ptr(out), dt_code(dtype), n, c, h, w, cpad)
+    return out
+
+
 def nhwc_to_nchw(x):
     n, h, w, c = x.shape
     out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)

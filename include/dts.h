@@ -30,7 +30,8 @@ typedef void* dts_stream;
 enum dts_dtype { DTS_F32 = 0, DTS_BF16 = 1, DTS_F16 = 2 };
 enum dts_status { DTS_OK = 0, DTS_ERR_ARG = -1, DTS_ERR_LAUNCH = -2, DTS_ERR_UNSUPPORTED = -3 };
 
-#define DTS_ABI_VERSION 103        /* bumped with every change of a signature or of dts_conv_args (101: ev_start/ev_stop; 102: tuning knobs; 103: dts_cosine_rows) */
+#define DTS_ABI_VERSION 104        /* bumped with every change of a signature or of dts_conv_args (101: ev_start/ev_stop; 102: tuning knobs; 103: dts_cosine_rows; 104: dts_nchw_to_nhwc_pad,
+                                     head dim 512 in dts_attention) */
 int dts_version(void);            /* == DTS_ABI_VERSION of the build; a binding must refuse any other value */
 const char* dts_last_error(void);
 /* Tuning knobs (measurement aid; a knob only selects between kernels / block orders with identical results).  knob: index of
@@ -42,6 +43,8 @@ int dts_get_tuning(int knob);
 /* NCHW f32 -> NHWC dtype, and back. */
 int dts_nchw_to_nhwc(const float* src, void* dst, int dtype, int n, int c, int h, int w, dts_stream s);
 int dts_nhwc_to_nchw(const void* src, int dtype, float* dst, int n, int c, int h, int w, dts_stream s);
+/* NCHW f32 -> NHWC dtype with the channel count padded to cpad (zeros): SD latents (4 channels) feeding the MFMA conv (cin % 64 == 0). */
+int dts_nchw_to_nhwc_pad(const float* src, void* dst, int dtype, int n, int c, int h, int w, int cpad, dts_stream s);
 /* OIHW f32 conv weight (torch layout, networks.py:62 / unet.py conv_nd) -> [O][kh][kw][I] dtype.
  * out_perm (device int32[O], nullable): packed row o is taken from source row out_perm[o]; used to
  * regroup the qkv projection's output channels into q|k|v blocks (networks.py:182, unet.py:365). */
@@ -108,7 +111,7 @@ int dts_resample2x(const void* x, void* out, int dtype, int n, int h, int w, int
 
 /* ---- K6: fused self-attention (networks.py:113-118,181-185; unet.py:355-372,388-407) -------------- */
 /* qkv NHWC-flattened [n][t][3*heads*d] laid out q[heads][d] | k[heads][d] | v[heads][d];
- * out [n][t][heads*d]; softmax(q.k * scale) in f32. d in {64,128,256}; any t >= 1. */
+ * out [n][t][heads*d]; softmax(q.k * scale) in f32. d in {64,128,256} (and 512 in the 16-bit types: the SD VAE's mid block); any t >= 1. */
 int dts_attention(const void* qkv, void* out, int dtype, int n, int t, int heads, int d, float scale, dts_stream s);
 
 /* ---- K7/K8: embedding MLP pieces and EDM preconditioning (networks.py:200-206,437-447,654-668) ---- */
