@@ -172,3 +172,52 @@ def checksum(sd):
         a += float(v64.abs().sum())
         n += v.numel()
     return dict(sum=s, abs_sum=a, numel=n)
+
+
+def vae_decoder_state_dict(block_out_channels=(128, 256, 512, 512), layers_per_block=2, latent_channels=4, seed=0):
+    """Random-init parameters of the SD VAE *decoder* (+ post_quant_conv) under diffusers' key names
+    (sd/diffusers/src/diffusers/models/autoencoders/vae.py:204-279, autoencoder_kl.py:105-110): BASELINE config 4 prescribes
+    random-init weights (SD-1.5's cannot be fetched).  Own seeded initialiser, fan-in scaled so activations stay O(1) through the
+    17 residual blocks; norms near identity.  Keys in construction order."""
+    g = torch.Generator().manual_seed(seed)
+    sd = OrderedDict()
+
+    def conv(key, cout, cin, k, gain=1.0):
+        sd[key + '.weight'] = torch.randn(cout, cin, k, k, generator=g) * (gain / math.sqrt(cin * k * k))
+        sd[key + '.bias'] = torch.randn(cout, generator=g) * 0.05
+
+    def lin(key, cout, cin, gain=1.0):
+        sd[key + '.weight'] = torch.randn(cout, cin, generator=g) * (gain / math.sqrt(cin))
+        sd[key + '.bias'] = torch.randn(cout, generator=g) * 0.05
+
+    def norm(key, c):
+        sd[key + '.weight'] = 1.0 + 0.1 * torch.randn(c, generator=g)
+        sd[key + '.bias'] = 0.1 * torch.randn(c, generator=g)
+
+    def resnet(key, cin, cout):
+        norm(key + '.norm1', cin); conv(key + '.conv1', cout, cin, 3)
+        norm(key + '.norm2', cout); conv(key + '.conv2', cout, cout, 3, gain=0.5)
+        if cin != cout:
+            conv(key + '.conv_shortcut', cout, cin, 1)
+
+    top = block_out_channels[-1]
+    conv('post_quant_conv', latent_channels, latent_channels, 1)
+    conv('decoder.conv_in', top, latent_channels, 3)
+    resnet('decoder.mid_block.resnets.0', top, top)
+    a = 'decoder.mid_block.attentions.0'
+    norm(a + '.group_norm', top)
+    for n in ('to_q', 'to_k', 'to_v'):
+        lin(a + '.' + n, top, top)
+    lin(a + '.to_out.0', top, top, gain=0.5)
+    resnet('decoder.mid_block.resnets.1', top, top)
+    rev = list(reversed(block_out_channels))
+    prev = rev[0]
+    for i, c in enumerate(rev):
+        for j in range(layers_per_block + 1):
+            resnet(f'decoder.up_blocks.{i}.resnets.{j}', prev if j == 0 else c, c)
+        if i != len(rev) - 1:
+            conv(f'decoder.up_blocks.{i}.upsamplers.0.conv', c, c, 3)
+        prev = c
+    norm('decoder.conv_norm_out', block_out_channels[0])
+    conv('decoder.conv_out', 3, block_out_channels[0], 3)
+    return sd

@@ -242,6 +242,25 @@ def test_attention(ops, dtype, shape):
     assert rel_err(out, ref) < (3e-5 if dtype == torch.float32 else TOL[dtype])
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('t', [64, 200, 1024])
+def test_attention_head_dim_512(ops, dtype, t):
+    """The SD VAE's mid-block attention: one head of dim 512 (two 256-wide value slices per query block, no register prefetch),
+    full and ragged sequence lengths."""
+    n, heads, d = 2, 1, 512
+    gen = g(16)
+    qkv = q(torch.randn(n, t, 3 * d, generator=gen), dtype)
+    qh = qkv[..., :d].permute(0, 2, 1)
+    kh = qkv[..., d:2 * d].permute(0, 2, 1)
+    vh = qkv[..., 2 * d:].permute(0, 2, 1)
+    w = onet.attention_weights(qh, kh)
+    ref = torch.einsum('nqk,nck->ncq', w, vh).permute(0, 2, 1)
+    out = ops.attention(qkv.to(DEV, dtype), heads, 1.0 / math.sqrt(d)).float().cpu()
+    assert rel_err(out, ref) < TOL[dtype]
+    with pytest.raises(RuntimeError):
+        ops.attention(qkv.to(DEV, torch.float32), heads, 1.0 / math.sqrt(d))        # head dim 512 is 16-bit only
+
+
 def test_linear_and_pos_embedding(ops):
     gen = g(7)
     x = torch.randn(5, 100, generator=gen)
