@@ -24,7 +24,7 @@
 #include <hip/hip_ext.h>
 #include <type_traits>
 
-static_assert(sizeof(dts_conv_args) == 160, "dts_conv_args layout changed: bump DTS_ABI_VERSION and update the bindings (_lib.py ConvArgs)");
+static_assert(sizeof(dts_conv_args) == 176, "dts_conv_args layout changed: bump DTS_ABI_VERSION and update the bindings (_lib.py ConvArgs)");
 
 namespace {
 
@@ -55,6 +55,8 @@ struct ConvP {
   float* stats;    // optional [ceil(P/64)][cout][2]: per 64-pixel strip (sum, sumsq) of the stored outputs (GroupNorm input)
   float out_scale;
   int w_shift, hw_shift;   // log2(wout), log2(hout*wout) when both are powers of two, else -1 (pixel coordinates by division)
+  const float* gn_coef;    // optional [n][cin][2] (a, b): GroupNorm of the INPUT applied on the staged halo tile (conv_pp_kernel only)
+  int gn_silu;
 };
 
 template <typename T> struct Mma;
@@ -676,6 +678,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
 #undef ISSUE_TILE
 #undef ADVANCE_K
 
+// act(x*a + b) on the 8 channels of one 16-byte LDS slot: the arithmetic of gn_apply_rows_kernel (groupnorm.hip) -- one fma, SiLU
+// through v_rcp for the 16-bit types, one rounding -- so fusing the apply into the conv does not change a bit of its input.
+template <typename T>
+__device__ __forceinline__ uint4 gn_act8(const uint4 v, const float (&ca)[8], const float (&cb)[8], int silu) {
+  float f[8];
+  unpack16<T>(v, f);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float y = f[e] * ca[e] + cb[e];
+    f[e] = silu ? y * __builtin_amdgcn_rcpf(1.0f + __expf(-y)) : y;
+  }
+  return pack16<T>(f);
+}
+
 // ------------------------------------------------------------------------------------------------------------------------------
 // Ping-pong + halo-tile variant (16-bit types, cout % 192 == 0, square power-of-two images >= 16, no fused upsample):
 // ONE 8-wave block per CU on a 192-cout x 256-pixel tile.  Two ideas, each answering a measurement (profiles/r02_conv_variants.txt):
@@ -710,11 +726,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
 //     and every older halo piece have landed; a 3x3 chunk issues no halo piece in its last three tiles, so the next chunk's halo is
 //     complete two tiles before its first LOAD; a 1x1 chunk is one tile, so there the wait is vmcnt(0).
 // Padding: halo rows outside the image get an out-of-range lane offset, which the buffer load turns into zeros.
+// FUSED GROUPNORM APPLY (kp.gn_coef, 3x3 only): the conv's input is the un-normalised tensor; every wave turns the halo pieces IT
+// staged into act(x*a + b) in place -- a piece is one 16-byte slot per lane, whose 8 channels are fixed for the lane, so its 16
+// coefficients sit in registers for the whole chunk -- two tiles after issuing them (the counted wait at the end of COMPUTE(j+1) has
+// retired piece j), between the MFMAs of COMPUTE(j+2), where the wave's vector issue slots are otherwise idle.  Padding rows are
+// skipped and stay zero, as in the reference (norm, then pad).  The halo is staged once per chunk, so this is one pass over the
+// input, not nine; the separate apply pass (read + write of the whole tensor, 3.6 ms of a 38 ms step) disappears.
 // The summation order over K differs from conv_igemm_kernel's (same terms, other f32 rounding order); it is fixed, so identical
 // inputs still give identical outputs (ties stay ties).
 // DBG != 0: timing-only diagnostic builds (outputs wrong by construction; tools/conv_bench.py conv_variant=11/21/41/51):
 //   1 = no LDS-DMA after the prologue, 2 = no MFMAs, 4 = every halo piece out of range, 5 = every A piece out of range
-template <typename T, int TAPS, int DBG = 0>
+template <typename T, int TAPS, int DBG = 0, bool GN = false>
 __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
   constexpr int MT = 6, NT = 4, BM = 192, BN = 256, NTHR = 512;
   constexpr int BKE = 64, ES = 2;
@@ -794,6 +816,28 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
     }
   }
   uint32_t hvo[NHP];                                   // lane offsets of the halo rows in the current source
+  uint32_t hval = 0;                                   // bit j: this lane's row of piece j is inside the image
+#pragma unroll
+  for (int j = 0; j < NHP; ++j) hval |= (hpix[j] >= 0 ? 1u : 0u) << j;
+  constexpr bool fuse_gn = GN && p_taps == 9;          // compile-time: the plain instantiation carries none of this
+  // GroupNorm coefficients of this lane's 8 channels (source chunk chunk ^ r0 of the 64-channel K chunk) for the halo being staged
+  float gca[8], gcb[8];
+  const float* const gn_base = fuse_gn ? kp.gn_coef + ((size_t)img0 * p_cin + 8 * (chunk ^ (r0 & 7))) * 2 : nullptr;
+  (void)gn_base; (void)hval;
+#define PP_LOAD_COEF(ci0_)                                                                                    \
+  {                                                                                                           \
+    const float4* q_ = reinterpret_cast<const float4*>(gn_base + (size_t)(ci0_) * 2);                         \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                           \
+      const float4 t_ = q_[e];                                                                                \
+      gca[2 * e] = t_.x; gcb[2 * e] = t_.y; gca[2 * e + 1] = t_.z; gcb[2 * e + 1] = t_.w;                     \
+    }                                                                                                         \
+  }
+  // in-place act(x*a+b) of this wave's piece j_ of the halo buffer at LDS byte offset hb_ (generic pointer smem + hb_)
+#define PP_GN_PIECE(j_, hb_)                                                                                  \
+  if ((hval >> (j_)) & 1u) {                                                                                  \
+    uint4* s_ = reinterpret_cast<uint4*>(smem + (hb_) + (size_t)(8 * (w + 8 * (j_))) * 128 + lane * 16);      \
+    *s_ = gn_act8<T>(*s_, gca, gcb, kp.gn_silu);                                                              \
+  }
   dts_i32x4 rs_x;                                      // descriptor of the current source (x1, or x2 past the concat boundary)
 #define PP_SET_SRC(ci0_)                                                                                      \
   {                                                                                                           \
@@ -846,6 +890,13 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
       if (w + 8 * j < npieces) bdma16(hvo[j], rs_x, so_, h_dst + j * (64 * 128));
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (fuse_gn) {                               // the first chunk's halo: every wave normalises the pieces it staged
+    PP_LOAD_COEF(ci0);
+#pragma unroll
+    for (int j = 0; j < NHP; ++j)
+      if (w + 8 * j < npieces) PP_GN_PIECE(j, H_OFF);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   asm volatile("s_barrier" ::: "memory");
   if (grp == 1) asm volatile("s_barrier" ::: "memory");          // the stagger: group 1 runs one segment behind group 0
 
@@ -862,7 +913,9 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
       // source may be switched now
       if ((next_ci0 >= p_c1) != (ci0 >= p_c1)) PP_SET_SRC(next_ci0);
       h_so = (uint32_t)(next_ci0 >= p_c1 ? next_ci0 - p_c1 : next_ci0) * ES;
+      if constexpr (fuse_gn) PP_LOAD_COEF(next_ci0);
     }
+    const uint32_t h_wr_off = (h_rd == H_OFF) ? H_OFF + H_BUF : H_OFF;                     // the same buffer as a byte offset in smem
 #pragma unroll 1
     for (int tap = 0; tap < p_taps; ++tap) {
       // ---------------- LOAD(t): fragments of tile t -> registers; DMA: this group's A rows, then (at most) its halo piece(s)
@@ -883,6 +936,10 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
       for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq));
 #pragma unroll
       for (int i = 0; i < MT; ++i) ga[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq + 4));
+      uint4 gv = make_uint4(0, 0, 0, 0);                 // fused GroupNorm: this wave's piece tap-2 of the next halo, read back here
+      const bool do_piece = fuse_gn && more && tap >= 2 && tap < NHP + 2 && w + 8 * (tap - 2) < npieces;   // wave-uniform
+      uint4* const gp = reinterpret_cast<uint4*>(smem + h_wr_off + (size_t)(8 * (w + 8 * (do_piece ? tap - 2 : 0))) * 128 + lane * 16);
+      if (do_piece) gv = *gp;
       int inflight = 0;                                  // pieces issued in this LOAD: they may still be flying when COMPUTE(t) ends
       if constexpr (DBG != 1) {
         if (t + 2 < nk) { PP_ISSUE_A(); inflight = 3; }        // A_g(t+2)
@@ -915,16 +972,30 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
 #pragma unroll
         for (int i = 0; i < NT; ++i) asm volatile("" ::"v"(fb[i].x), "v"(gb[i].w));
       } else {
+        // piece tap-2 of the next halo (issued in LOAD(tap-2), retired by the counted wait that ended COMPUTE(tap-1); read back in
+        // LOAD(tap) above) is normalised here: ~60 VALU instructions, 16 of them transcendental.  Branch-free per lane (a padding
+        // row selects its old zeros).  MEASURED (profiles/r02_gn_fusion.txt): hipcc schedules them as a block after the MFMAs, the
+        // matrix pipe idles meanwhile, and the conv loses more (+3.4 ms per step) than the separate apply pass cost (2.5 ms): the
+        // fused path is correct (bit-identical, tested) but OFF by default (DTS_GN_FUSE=1 turns it on in networks.py).
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
+        if constexpr (fuse_gn) {
+          if (do_piece) {
+            const uint4 gr = gn_act8<T>(gv, gca, gcb, kp.gn_silu);
+            const bool ok = (hval >> (tap - 2)) & 1u;
+            *gp = make_uint4(ok ? gr.x : gv.x, ok ? gr.y : gv.y, ok ? gr.z : gv.z, ok ? gr.w : gv.w);
+            // (forcing one MFMA : two VALU with sched_group_barrier made hipcc spill 342 VGPRs -- 835 evals/s; left to its scheduler)
+          }
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], ga[i], gb[j]);
       }
       __builtin_amdgcn_s_setprio(0);
+      if constexpr (fuse_gn) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the normalised piece is in LDS
       __builtin_amdgcn_sched_barrier(0);
       // everything issued before LOAD(t) has landed -- A_g(t+1), the older halo pieces; only LOAD(t)'s own pieces may fly on
       if (inflight == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -942,6 +1013,8 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
   if (grp == 0) asm volatile("s_barrier" ::: "memory");          // matches group 1's last COMPUTE barrier
 #undef PP_SET_SRC
 #undef PP_ISSUE_A
+#undef PP_LOAD_COEF
+#undef PP_GN_PIECE
   __syncthreads();
 
   conv_epilogue<T, MT, NT, BM, BN, NTHR>(kp, acc, cm0, tm, (int)blockIdx.y, wm, wn, lrow, lq, smem, bias_in_acc, 0, 0, 0);
@@ -1104,7 +1177,7 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, C
 }
 
 // ---- ping-pong launcher: one block per (192-cout tile, 256-pixel tile[, K split]); 512 threads, 136 KB of LDS
-template <typename T, int TAPS, int DBG = 0>
+template <typename T, int TAPS, int DBG = 0, bool GN = false>
 int launch_conv_pp(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, ConvCall& call) {
   if constexpr (sizeof(T) != 2) {
     return DTS_ERR_UNSUPPORTED;
@@ -1141,13 +1214,13 @@ int launch_conv_pp(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes
     constexpr size_t lds = (size_t)(6 * 96 + 2 * 328) * 128;      // A: 2 groups x 3 slots x 96 rows; halo: 2 buffers x 328 rows
     static bool attr_done = false;
     if (!attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<T, TAPS, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<T, TAPS, DBG, GN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_done = true;
     }
     if (call.ev_start != nullptr && call.ev_stop != nullptr)
-      hipExtLaunchKernelGGL((conv_pp_kernel<T, TAPS, DBG>), dim3(nblk, splits), dim3(512), lds, st, call.ev_start, call.ev_stop, 0, q);
+      hipExtLaunchKernelGGL((conv_pp_kernel<T, TAPS, DBG, GN>), dim3(nblk, splits), dim3(512), lds, st, call.ev_start, call.ev_stop, 0, q);
     else
-      hipLaunchKernelGGL((conv_pp_kernel<T, TAPS, DBG>), dim3(nblk, splits), dim3(512), lds, st, q);
+      hipLaunchKernelGGL((conv_pp_kernel<T, TAPS, DBG, GN>), dim3(nblk, splits), dim3(512), lds, st, q);
     DTS_CHECK_LAUNCH("dts_conv2d(ping-pong)");
     if (splits > 1 && stats_in_reduce) {
       q.stats = stats_req;
@@ -1172,6 +1245,14 @@ int conv_dispatch_tile(const ConvP& p, int tile, hipStream_t st, float* ws, long
   }
 }
 
+// the shapes the ping-pong / halo kernel takes (and with it the fused GroupNorm apply)
+bool conv_pp_eligible(int dtype, int ksize, int cout, int c1, int c2, int n, int hin, int win, int up) {
+  const long long P = (long long)n * hin * win;
+  return dtype != DTS_F32 && cout % 192 == 0 && !up && hin == win && win >= 16 && (win & (win - 1)) == 0 && P % 256 == 0 &&
+         (long long)n * hin * win * (c1 > c2 ? c1 : c2) * 2 < (1ll << 31) && (long long)cout * ksize * ksize * (c1 + c2) * 2 < (1ll << 31) &&
+         (c1 % 64 == 0) && (c2 % 64 == 0);
+}
+
 template <typename T>
 int conv_dispatch(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, ConvCall& call) {
   const int g_tile_override = dts_knob_get(DTS_KNOB_CONV_TILE);     // DTS_CONV_TILE=64|128|192 (tuning aid; only honoured when it divides cout)
@@ -1181,17 +1262,17 @@ int conv_dispatch(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes,
   // DTS_CONV_VARIANT: 1 = the 8-wave ping-pong kernel wherever it applies (16-bit, cout % 192 == 0), 0 = never, unset = by shape
   const int variant = dts_knob_get(DTS_KNOB_CONV_VARIANT);
   // ping-pong / halo kernel: square power-of-two images of 16..., whole 256-pixel tiles, 32-bit lane offsets, no fused upsample
-  const bool pp_ok = !p.up && p.hin == p.win && p.win >= 16 && (p.win & (p.win - 1)) == 0 && p.P % 256 == 0 &&
-                     (long long)p.n * p.hin * p.win * (p.c1 > p.c2 ? p.c1 : p.c2) * 2 < (1ll << 31) &&
-                     (long long)p.cout * p.taps * p.cin * 2 < (1ll << 31);
+  const bool pp_ok = conv_pp_eligible(std::is_same<T, float>::value ? DTS_F32 : DTS_BF16, p.taps == 9 ? 3 : 1, p.cout, p.c1, p.c2, p.n,
+                                      p.hin, p.win, p.up);
   if (!std::is_same<T, float>::value && p.cout % 192 == 0 && g_tile_override <= 0 && pp_ok) {
     const long long blocks_pp = (long long)(p.cout / 192) * ((p.P + 255) / 256);
     // measured (tools/conv_bench.py --variants, profiles/r02_conv_variants.txt): 3x3 layers +3..11 %, 1x1 layers -10..15 % (their
     // 6-12 K tiles do not amortise the exposed prologue/epilogue of a one-block-per-CU kernel): 3x3 only
     // with a residual input the epilogue's residual fetch is exposed here (no early fetch yet): short-K layers (K = 1728) then lose
     // 2-3 % to conv_igemm_kernel, longer ones still gain
-    const bool auto_pp = p.taps == 9 && (p.residual == nullptr || p.cin >= 384);
+    const bool auto_pp = p.taps == 9 && (p.residual == nullptr || p.cin >= 384 || p.gn_coef != nullptr);
 #define DTS_PP(DBG_) (p.taps == 9 ? launch_conv_pp<T, 9, DBG_>(p, st, ws, ws_bytes, call) : launch_conv_pp<T, 1, DBG_>(p, st, ws, ws_bytes, call))
+    if (p.gn_coef != nullptr) return launch_conv_pp<T, 9, 0, true>(p, st, ws, ws_bytes, call);      // dts_conv2d has checked dts_conv_fuses_gn
     if (variant == 1 || (variant < 0 && auto_pp && blocks_pp >= 64)) return DTS_PP(0);
     if (variant == 11) return DTS_PP(1);     // timing-only diagnostics
     if (variant == 21) return DTS_PP(2);
@@ -1207,6 +1288,15 @@ int conv_dispatch(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes,
 }
 
 }  // namespace
+
+extern "C" int dts_conv_fuses_gn(const dts_conv_args* a) {
+  if (a == nullptr || a->ksize != 3) return 0;
+  const int variant = dts_knob_get(DTS_KNOB_CONV_VARIANT);
+  if (variant == 0 || dts_knob_get(DTS_KNOB_CONV_TILE) > 0) return 0;
+  if (!conv_pp_eligible(a->dtype, a->ksize, a->cout, a->c1, a->c2, a->n, a->hin, a->win, a->up)) return 0;
+  const long long blocks_pp = (long long)(a->cout / 192) * (((long long)a->n * a->hin * a->win + 255) / 256);
+  return (variant == 1 || blocks_pp >= 64) ? 1 : 0;              // with gn_coef the kernel choice does not depend on the residual
+}
 
 extern "C" int dts_conv2d(dts_conv_args* a, dts_stream s) {
   DTS_CHECK_ARG(a != nullptr, "dts_conv2d: null args");
@@ -1239,6 +1329,9 @@ extern "C" int dts_conv2d(dts_conv_args* a, dts_stream s) {
     const int hw = p.hout * p.wout;
     if ((p.wout & (p.wout - 1)) == 0 && (hw & (hw - 1)) == 0) { p.w_shift = __builtin_ctz(p.wout); p.hw_shift = __builtin_ctz(hw); }
   }
+  p.gn_coef = a->gn_coef; p.gn_silu = a->gn_silu;
+  DTS_CHECK_ARG(a->gn_coef == nullptr || dts_conv_fuses_gn(a), "dts_conv2d: gn_coef given for a launch that cannot fuse the GroupNorm apply "
+                "(ask dts_conv_fuses_gn first)");
   p.stats = a->stats_out;
   DTS_CHECK_ARG(a->stats_out == nullptr || ((p.hout * p.wout) % 64 == 0 && (uintptr_t)a->stats_out % 16 == 0),
                 "dts_conv2d: strip statistics need hout*wout to be a multiple of 64 and a 16-byte aligned buffer");

@@ -17,6 +17,7 @@ and the channel concat of the decoder (networks.py:458) is never materialised: t
 conv read both sources.
 """
 import math
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -53,6 +54,9 @@ class EDMPrecond:
         self.eps = 1e-5 if self.adm else 1e-6
         self.skip_scale = 1.0 if self.adm else math.sqrt(0.5)
         self.evals = 0                               # rows pushed through the denoiser (BASELINE metric unit)
+        # GroupNorm apply inside the consuming 3x3 conv (built, bit-identical, tested) -- OFF by default: measured slower than the
+        # separate apply pass (profiles/r02_gn_fusion.txt); DTS_GN_FUSE=1 turns it on
+        self.fuse_gn = os.environ.get('DTS_GN_FUSE', '0') == '1'
         from .graphs import GraphCache
         self._graphs = GraphCache(self._device_forward)     # HIP-graph replay of the fixed-shape forward (graphs.py)
         sd = {k[len('model.'):]: v for k, v in state_dict.items() if k.startswith('model.')}
@@ -165,9 +169,20 @@ class EDMPrecond:
         P = self.blocks[b.name]
         G = self._groups
         ss = aff[:, P.aff_off:P.aff_off + P.caff]
-        h = ops.group_norm(x1, G(b.cin), self.eps, P.g0, P.b0, x2=x2, silu=True, pool=b.down)
-        h = ops.conv2d(h, P.w0, P.cb0, up=b.up, bias_nc=None if self.adm else ss, gn_stats=True)
-        h = ops.group_norm(h, G(b.cout), self.eps, P.g1, P.b1, scale_shift=ss if self.adm else None, silu=True)
+        bnc = None if self.adm else ss
+        if self.fuse_gn and not b.down and ops.conv_fuses_gn(x1, P.w0, x2=x2, up=b.up):
+            # norm0 + SiLU applied inside conv0 on its staged input tile: the normalised (and, in the decoder, concatenated) tensor
+            # is never written (networks.py:168)
+            coef = ops.gn_coefficients(x1, G(b.cin), self.eps, P.g0, P.b0, x2=x2)
+            h = ops.conv2d(x1, P.w0, P.cb0, x2=x2, up=b.up, bias_nc=bnc, gn_stats=True, gn_coef=coef, gn_silu=True)
+        else:
+            h = ops.group_norm(x1, G(b.cin), self.eps, P.g0, P.b0, x2=x2, silu=True, pool=b.down)
+            h = ops.conv2d(h, P.w0, P.cb0, up=b.up, bias_nc=bnc, gn_stats=True)
+        fuse1 = self.fuse_gn and ops.conv_fuses_gn(h, P.w1)
+        if fuse1:        # norm1 (+ adaptive scale/shift) + SiLU inside conv1 (networks.py:173-175)
+            coef1 = ops.gn_coefficients(h, G(b.cout), self.eps, P.g1, P.b1, scale_shift=ss if self.adm else None)
+        else:
+            h = ops.group_norm(h, G(b.cout), self.eps, P.g1, P.b1, scale_shift=ss if self.adm else None, silu=True)
         if P.skip_w is not None:
             src1, src2 = (ops.resample2x(x1, up=False), None) if b.down else (x1, x2)
             sk = ops.conv2d(src1, P.skip_w, P.skip_b, x2=src2, up=b.up)
@@ -175,7 +190,8 @@ class EDMPrecond:
             sk = ops.resample2x(x1, up=b.up)
         else:
             sk = x1
-        x = ops.conv2d(h, P.w1, P.cb1, residual=sk, out_scale=self.skip_scale, gn_stats=True)
+        x = ops.conv2d(h, P.w1, P.cb1, residual=sk, out_scale=self.skip_scale, gn_stats=True,
+                       gn_coef=coef1 if fuse1 else None, gn_silu=True)
         if b.heads:
             n, hh, ww, c = x.shape
             hn = ops.group_norm(x, G(c), self.eps, P.g2, P.b2, silu=False)

@@ -100,8 +100,23 @@ def _conv_workspace(device):
     return ws
 
 
+def _conv_args(x1, w, x2, up):
+    n, hin, win, c1 = x1.shape
+    a = L.ConvArgs()
+    a.c1, a.c2 = c1, 0 if x2 is None else x2.shape[-1]
+    a.n, a.hin, a.win, a.cout, a.ksize = n, hin, win, w.shape[0], w.shape[1]
+    a.up, a.dtype = int(up), dt_code(x1.dtype)
+    return a
+
+
+def conv_fuses_gn(x1, w, *, x2=None, up=False):
+    """True if conv2d(x1, w, ..., gn_coef=...) applies the GroupNorm of its input inside the kernel for this shape / dtype
+    (the ping-pong / halo kernel: 3x3, cout % 192 == 0, 16-bit, square power-of-two images >= 16, no fused upsample)."""
+    return bool(L.load().dts_conv_fuses_gn(C.byref(_conv_args(x1, w, x2, up))))
+
+
 def conv2d(x1, w, bias=None, *, x2=None, bias_nc=None, residual=None, up=False, out_scale=1.0, out=None, gn_stats=False,
-           timing_events=None):
+           timing_events=None, gn_coef=None, gn_silu=True):
     """timing_events=(start, stop): raw hipEvent_t handles attached to the conv kernel's own dispatch (measurement only).
     gn_stats=True: the epilogue also emits the GroupNorm moments of the output (per 64-pixel strip and channel); they
     ride on the returned tensor as `out._gn_stats` (None when the launch could not produce them) and are consumed by
@@ -134,6 +149,10 @@ def conv2d(x1, w, bias=None, *, x2=None, bias_nc=None, residual=None, up=False, 
         a.stats_out = st.data_ptr()
     if timing_events is not None:
         a.ev_start, a.ev_stop = timing_events
+    if gn_coef is not None:       # GroupNorm (+SiLU) of the input applied on the staged tile: only where conv_fuses_gn() says so
+        if tuple(gn_coef.shape) != (n, c1 + c2, 2):
+            raise ValueError(f'conv2d: gn_coef shape {tuple(gn_coef.shape)} != {(n, c1 + c2, 2)}')
+        a.gn_coef, a.gn_silu = _ptr(gn_coef, 'gn_coef', torch.float32), int(gn_silu)
     _call('dts_conv2d', C.byref(a))
     out._gn_stats = st if (st is not None and a.stats_written) else None
     return out
@@ -185,21 +204,40 @@ def gn_apply(x1, coef, *, x2=None, silu=True, pool=False):
 GN_FUSED_MAX_HW = 64        # 8x8 levels take the single-launch kernel (measured: tools/gn_bench.py; larger levels are bandwidth-bound)
 
 
+def _coef_from_strips(x1, x2, groups, eps, gamma, beta, scale_shift):
+    """coef [n, C, 2] from the strip statistics the producing convolutions attached to x1 (and x2), or None."""
+    n, h, w, c1 = x1.shape
+    c2 = 0 if x2 is None else x2.shape[-1]
+    st1 = getattr(x1, '_gn_stats', None)
+    st2 = None if x2 is None else getattr(x2, '_gn_stats', None)
+    if st1 is None or (x2 is not None and st2 is None) or (h * w) % 64 != 0:
+        return None
+    coef = torch.empty((n, c1 + c2, 2), dtype=torch.float32, device=x1.device)
+    ss_ptr, ss_ld = _rows(scale_shift, 'scale_shift', x1.dtype)
+    _call('dts_gn_coef_strips', _ptr(st1, 'st1', torch.float32), c1, _ptr(st2, 'st2', torch.float32), c2, dt_code(x1.dtype), n,
+          h * w, groups, float(eps), _ptr(gamma, 'gamma', torch.float32), _ptr(beta, 'beta', torch.float32), ss_ptr, ss_ld,
+          _ptr(coef))
+    return coef
+
+
+def gn_coefficients(x1, groups, eps, gamma, beta, *, x2=None, scale_shift=None):
+    """The GroupNorm of concat(x1, x2) as per-(sample, channel) coefficients (a, b): norm(x)*gamma+beta [*(1+scale)+shift] == x*a+b.
+    Taken from the producers' strip statistics when they are attached, else from a statistics pass over the tensor.  What
+    conv2d(..., gn_coef=) consumes when the consuming convolution applies the norm itself (conv_fuses_gn)."""
+    coef = _coef_from_strips(x1, x2, groups, eps, gamma, beta, scale_shift)
+    return coef if coef is not None else gn_coef(x1, groups, eps, gamma, beta, x2=x2, scale_shift=scale_shift)
+
+
 def group_norm(x1, groups, eps, gamma, beta, *, x2=None, scale_shift=None, silu=True, pool=False, path=None):
     """GroupNorm [+ (1+scale), shift] [+ SiLU] [+ 2x2 average pool].  path: None = auto, 'fused' | 'split' (tests)."""
     n, h, w, c1 = x1.shape
     c2 = 0 if x2 is None else x2.shape[-1]
     cg = (c1 + c2) // groups
     fused_ok = (not pool) and cg % 2 == 0 and cg <= 64
-    st1 = getattr(x1, '_gn_stats', None)
-    st2 = None if x2 is None else getattr(x2, '_gn_stats', None)
-    if path in (None, 'strips') and st1 is not None and (x2 is None or st2 is not None) and (h * w) % 64 == 0:
-        coef = torch.empty((n, c1 + c2, 2), dtype=torch.float32, device=x1.device)
-        ss_ptr, ss_ld = _rows(scale_shift, 'scale_shift', x1.dtype)
-        _call('dts_gn_coef_strips', _ptr(st1, 'st1', torch.float32), c1, _ptr(st2, 'st2', torch.float32), c2, dt_code(x1.dtype), n,
-              h * w, groups, float(eps), _ptr(gamma, 'gamma', torch.float32), _ptr(beta, 'beta', torch.float32), ss_ptr, ss_ld,
-              _ptr(coef))
-        return gn_apply(x1, coef, x2=x2, silu=silu, pool=pool)
+    if path in (None, 'strips'):
+        coef = _coef_from_strips(x1, x2, groups, eps, gamma, beta, scale_shift)
+        if coef is not None:
+            return gn_apply(x1, coef, x2=x2, silu=silu, pool=pool)
     if path == 'strips':
         raise ValueError('strip statistics are not attached to the input(s)')
     if path is None:

@@ -30,7 +30,8 @@ typedef void* dts_stream;
 enum dts_dtype { DTS_F32 = 0, DTS_BF16 = 1, DTS_F16 = 2 };
 enum dts_status { DTS_OK = 0, DTS_ERR_ARG = -1, DTS_ERR_LAUNCH = -2, DTS_ERR_UNSUPPORTED = -3 };
 
-#define DTS_ABI_VERSION 104        /* bumped with every change of a signature or of dts_conv_args (101: ev_start/ev_stop; 102: tuning knobs; 103: dts_cosine_rows; 104: dts_nchw_to_nhwc_pad,
+#define DTS_ABI_VERSION 105        /* bumped with every change of a signature or of dts_conv_args (101: ev_start/ev_stop; 102: tuning knobs; 103: dts_cosine_rows; 104: dts_nchw_to_nhwc_pad,
+                                     105: dts_conv_args.gn_coef / gn_silu, dts_conv_fuses_gn;
                                      head dim 512 in dts_attention) */
 int dts_version(void);            /* == DTS_ABI_VERSION of the build; a binding must refuse any other value */
 const char* dts_last_error(void);
@@ -75,7 +76,15 @@ typedef struct dts_conv_args {
                                      emit the statistics from their reduce pass */
   void* ev_start; void* ev_stop;  /* optional hipEvent_t pair attached to the conv kernel's own dispatch (start / end of that kernel, as a
                                      kernel trace sees it; no barrier packets between launches).  Measurement only: bench.py's roofline leg */
+  const float* gn_coef;           /* optional [n][c1+c2][2] f32 (a, b) from dts_gn_coef / dts_gn_coef_strips: the GroupNorm (+ adaptive
+                                     scale/shift) of the INPUT, applied as act(x*a + b) while the conv stages its input tile, so the
+                                     normalised tensor is never written (networks.py:168,173-175 feeding conv0 / conv1).  Only launches
+                                     for which dts_conv_fuses_gn() returns 1 accept it; padding stays zero (the reference pads AFTER the norm) */
+  int32_t gn_silu;                /* 1: act = SiLU, 0: identity */
 } dts_conv_args;
+/* 1 if dts_conv2d would apply a->gn_coef inside the conv for this shape / dtype (3x3, cout % 192 == 0, 16-bit, square power-of-two
+ * images >= 16, whole 256-pixel tiles, no fused upsample), else 0: the caller then runs dts_gn_apply first. */
+int dts_conv_fuses_gn(const dts_conv_args* a);
 int dts_conv2d(dts_conv_args* a, dts_stream s);      /* writes a->stats_written; no state is kept between calls (thread-safe) */
 
 /* first / last convolutions of the U-Nets (3 image channels; direct, not MFMA) */

@@ -146,6 +146,53 @@ def test_conv_epilogue_emits_group_norm_statistics(ops, dtype):
     assert rel_err(a2.float().cpu(), b2_.float().cpu()) < (1e-5 if dtype == torch.float32 else 2e-2)
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('res,c1,c2,cout', [(16, 128, 0, 192), (32, 64, 128, 384), (64, 192, 0, 192)])
+def test_conv_applies_group_norm_of_its_input(ops, dtype, res, c1, c2, cout):
+    """GroupNorm (+ adaptive scale/shift) + SiLU of the input applied inside the 3x3 conv on its staged halo tile == the separate
+    apply pass followed by the conv, BIT FOR BIT (same arithmetic, same rounding); image borders stay zero-padded; concat input."""
+    gen = g(31)
+    n = 2 if res < 64 else 1
+    C_ = c1 + c2
+    x1 = q(torch.randn(n, c1, res, res, generator=gen) * 1.5 + 0.3, dtype)
+    x2 = q(torch.randn(n, c2, res, res, generator=gen), dtype) if c2 else None
+    wt = q(torch.randn(cout, C_, 3, 3, generator=gen) / math.sqrt(C_ * 9), dtype)
+    bias = torch.randn(cout, generator=gen)
+    gamma, beta = torch.randn(C_, generator=gen), torch.randn(C_, generator=gen)
+    ss = q(torch.randn(n, 2 * C_, generator=gen) * 0.3, dtype).to(DEV, dtype).contiguous()
+    x1d, x2d = to_nhwc(ops, x1, dtype), (to_nhwc(ops, x2, dtype) if c2 else None)
+    wp = ops.pack_conv_weight(wt.to(DEV), dtype)
+    from diffusion_tts_amd import _lib
+    _lib.set_tuning('conv_variant', 1)            # the small test grids are below the launcher's block-count threshold for this kernel
+    try:
+        _check_fused_gn(ops, dtype, n, C_, x1, x2, x1d, x2d, wt, wp, bias, gamma, beta, ss, gen)
+    finally:
+        _lib.set_tuning('conv_variant', -1)
+
+
+def _check_fused_gn(ops, dtype, n, C_, x1, x2, x1d, x2d, wt, wp, bias, gamma, beta, ss, gen):
+    c2 = 0 if x2 is None else x2.shape[1]
+    assert ops.conv_fuses_gn(x1d, wp, x2=x2d)
+    coef = ops.gn_coefficients(x1d, 32, 1e-5, gamma.to(DEV), beta.to(DEV), x2=x2d, scale_shift=ss)
+    fused = ops.conv2d(x1d, wp, bias.to(DEV), x2=x2d, gn_coef=coef, gn_silu=True, gn_stats=True)
+    h = ops.gn_apply(x1d, coef, x2=x2d, silu=True)
+    plain = ops.conv2d(h, wp, bias.to(DEV), gn_stats=True)
+    assert torch.equal(fused, plain)
+    assert torch.allclose(fused._gn_stats, plain._gn_stats)
+    # and against the oracle's group norm + conv
+    xin = torch.cat([x1, x2], 1) if c2 else x1
+    hn = onet.group_norm(xin, gamma, beta, 1e-5)
+    hn = onet.silu(hn * (1 + ss.float().cpu()[:, :C_, None, None]) + ss.float().cpu()[:, C_:, None, None])
+    ref = onet.conv2d(hn, wt, bias)
+    assert rel_err(from_nhwc(ops, fused), ref) < TOL[dtype]
+    # shapes the kernel does not take are refused, not silently mis-computed
+    small = to_nhwc(ops, q(torch.randn(1, 64, 8, 8, generator=gen), dtype), dtype)
+    w8 = ops.pack_conv_weight(q(torch.randn(192, 64, 3, 3, generator=gen), dtype).to(DEV), dtype)
+    assert not ops.conv_fuses_gn(small, w8)
+    with pytest.raises(RuntimeError):
+        ops.conv2d(small, w8, None, gn_coef=torch.zeros(1, 64, 2, device=DEV))
+
+
 def test_conv2d_identical_rows_are_bit_identical(ops):
     """ties must stay ties: the same candidate at different batch positions gives the same bits."""
     gen = g(2)
