@@ -184,10 +184,18 @@ def conv_roofline(a, run_once, reps, dtype_name, value_per_gpu, gflop_per_eval, 
         e0, e1 = hev.pair()
         out = orig(x1, w, bias, timing_events=(e0, e1), **kw)
         n_, ho, wo, co = out.shape
+        es = out.element_size()
+        cin = w.shape[3]
+        # algorithmic bytes of the launch: every input / weight / residual byte read once, every output byte written once
+        alg = es * (x1.numel() + (kw['x2'].numel() if kw.get('x2') is not None else 0) + w.numel() + out.numel() +
+                    (out.numel() if kw.get('residual') is not None else 0))
+        # which kernel the launcher picks (csrc/conv_igemm.hip conv_dispatch): the ping-pong / halo kernel for eligible 3x3 layers
+        pp = w.shape[1] == 3 and ops.conv_fuses_gn(x1, w, x2=kw.get('x2'), up=bool(kw.get('up'))) and \
+            (kw.get('residual') is None or cin >= 384 or kw.get('gn_coef') is not None)
         rec.append((2.0 * n_ * ho * wo * co * w.shape[1] * w.shape[2] * w.shape[3], e0, e1,
                     (tuple(x1.shape), tuple(w.shape), 'x2' if kw.get('x2') is not None else '', 'up' if kw.get('up') else '',
                      'res' if kw.get('residual') is not None else '', 'bnc' if kw.get('bias_nc') is not None else '',
-                     'stats' if kw.get('gn_stats') else '')))
+                     'stats' if kw.get('gn_stats') else ''), alg, 'conv_pp_kernel' if pp else 'conv_igemm_kernel'))
         return out
     ops.conv2d = timed_conv
     was = [c.enabled for c in extra_caches]
@@ -210,23 +218,38 @@ def conv_roofline(a, run_once, reps, dtype_name, value_per_gpu, gflop_per_eval, 
             t[0] += 1; t[1] += r[0]; t[2] += hev.elapsed_ms(r[1], r[2])
         for k_, (c_, f_, m_) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
             log(f'conv {str(k_):100s} x{c_:4d}  {m_ / reps:7.3f} ms/step  {f_ / m_ / 1e9:7.1f} TFLOP/s')
-    hev.close()
     ach = fl / (ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[dtype_name]
+    per_kernel = {}
+    for r in rec:                           # per conv kernel: launches, time, algorithmic FLOPs and bytes (the PMC bytes are per kernel name)
+        k_ = per_kernel.setdefault(r[5], dict(launches=0, ms=0.0, gflop=0.0, alg_mb=0.0))
+        k_['launches'] += 1; k_['ms'] += hev.elapsed_ms(r[1], r[2]); k_['gflop'] += r[0] / 1e9; k_['alg_mb'] += r[4] / 1e6
+    hev.close()
+    kernels = {k_: dict(launches=v['launches'], tflops=round(v['gflop'] / max(v['ms'], 1e-9), 1), avg_launch_us=round(v['ms'] * 1e3 / v['launches'], 2),
+                        alg_mb_per_launch=round(v['alg_mb'] / v['launches'], 1)) for k_, v in per_kernel.items()}
+    dom_family = max(per_kernel, key=lambda k_: per_kernel[k_]['ms'])
     traffic, tsrc = None, None
     try:        # HBM bytes per launch of the dominant kernel: a STATIC figure from committed rocprofv3 --pmc passes of this very
         # command (counters cannot be collected from inside the process), valid for the default workload/dtype only
         with open(os.path.join(ROOT, TRAFFIC_PROFILE)) as f:
             doc = json.load(f)
         if a.workload == 'adm64_eps_greedy' and dtype_name == 'bf16' and a.candidates == 64 and a.gpus == 1:
-            traffic = round(doc['dominant']['hbm_bytes_per_launch'])
+            traffic = round(doc['kernels_by_family'][dom_family]['hbm_bytes_per_launch'])
             tsrc = f'static, from {TRAFFIC_PROFILE} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; not measured in this run)'
     except Exception:
         pass
-    return {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-            'traffic': traffic, 'traffic_source': tsrc, 'kernel': 'conv_igemm_kernel', 'launches': len(rec),
-            'avg_launch_us': round(ms * 1e3 / max(1, len(rec)), 2), 'avg_launch_gflop': round(fl / max(1, len(rec)) / 1e9, 3),
-            'conv_ms_per_step': round(ms / reps, 2),
+    # the DOMINANT kernel = the conv kernel with the most time in the step (conv_pp_kernel on the ADM workload: the 3x3 layers); its
+    # numbers are the top-level ones (what `rocprofv3 --kernel-trace --stats` reports for that kernel name must agree with avg_launch_us);
+    # the aggregate over every implicit-GEMM conv launch of the step is kept beside it
+    dom = max(per_kernel, key=lambda k_: per_kernel[k_]['ms'])
+    d = per_kernel[dom]
+    dach = d['gflop'] / d['ms']            # GFLOP / ms = TFLOP/s
+    return {'bound': 'mfma', 'achieved': round(dach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(dach / peak, 4),
+            'traffic': traffic, 'traffic_source': tsrc, 'kernel': dom, 'launches': d['launches'],
+            'avg_launch_us': round(d['ms'] * 1e3 / d['launches'], 2), 'avg_launch_gflop': round(d['gflop'] / d['launches'], 3),
+            'alg_mb_per_launch': round(d['alg_mb'] / d['launches'], 1), 'ms_per_step': round(d['ms'] / reps, 2),
+            'all_conv': {'achieved': round(ach, 1), 'frac': round(ach / peak, 4), 'launches': len(rec),
+                         'avg_launch_us': round(ms * 1e3 / max(1, len(rec)), 2), 'conv_ms_per_step': round(ms / reps, 2), 'kernels': kernels},
             'whole_step_frac': round(value_per_gpu * gflop_per_eval * 1e9 / (peak * 1e12), 4)}
 
 

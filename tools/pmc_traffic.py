@@ -43,8 +43,15 @@ def main():
         write = wt[k] * 1024 / wc[k]
         kernels[short(k)] = {'launches': fc[k], 'fetch_size_bytes_per_launch': fetch, 'fetch_corrected_x2': 2 * fetch,
                              'write_size_bytes_per_launch': write, 'hbm_bytes_per_launch': 2 * fetch + write}
-    doc = {'command': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 '
-                      '--no-cpu-baseline --no-kernel-timing',
+    # per conv kernel family (the name bench.py's roofline.kernel uses), launch-weighted over its template instantiations
+    fam = {}
+    for famname in ('conv_pp_kernel', 'conv_igemm_kernel'):
+        ks = [v for k, v in kernels.items() if k.startswith(famname)]
+        nl = sum(v['launches'] for v in ks)
+        if nl:
+            fam[famname] = {'launches': nl, 'hbm_bytes_per_launch': sum(v['hbm_bytes_per_launch'] * v['launches'] for v in ks) / nl}
+    doc = {'kernels_by_family': fam, 'command': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 '
+                      '--no-cpu-baseline --no-kernel-timing --no-e2e',
            'note': 'FETCH_SIZE/WRITE_SIZE are KiB; gfx950 reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM), hence '
                    'fetch_corrected_x2; Infinity-Cache hits are counted too, so this is an upper bound on HBM reads',
            'kernels': dict(list(kernels.items())[:14])}
