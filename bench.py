@@ -64,6 +64,7 @@ def parse(argv=None):
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-e2e', action='store_true')
     ap.add_argument('--no-weak', action='store_true', help='skip the weak-scaling leg of a multi-rank run')
+    ap.add_argument('--conv-sequence', default=None, help='write the per-launch conv shape sequence of one step (JSON) for tools/pmc_traffic.py')
     ap.add_argument('--conv-table', action='store_true', help='log the per-shape conv launch table of the instrumented steps')
     ap.add_argument('--cpu-sample', type=int, default=64, help='candidates in the CPU-baseline / parity iteration')
     a = ap.parse_args(argv)
@@ -195,7 +196,8 @@ def conv_roofline(a, run_once, reps, dtype_name, value_per_gpu, gflop_per_eval, 
         rec.append((2.0 * n_ * ho * wo * co * w.shape[1] * w.shape[2] * w.shape[3], e0, e1,
                     (tuple(x1.shape), tuple(w.shape), 'x2' if kw.get('x2') is not None else '', 'up' if kw.get('up') else '',
                      'res' if kw.get('residual') is not None else '', 'bnc' if kw.get('bias_nc') is not None else '',
-                     'stats' if kw.get('gn_stats') else ''), alg, 'conv_pp_kernel' if pp else 'conv_igemm_kernel'))
+                     'stats' if kw.get('gn_stats') else ''), alg,
+                    'conv_pp_kernel' if pp else ('conv_igemm_kernel/3x3' if w.shape[1] == 3 else 'conv_igemm_kernel/1x1')))
         return out
     ops.conv2d = timed_conv
     was = [c.enabled for c in extra_caches]
@@ -218,6 +220,12 @@ def conv_roofline(a, run_once, reps, dtype_name, value_per_gpu, gflop_per_eval, 
             t[0] += 1; t[1] += r[0]; t[2] += hev.elapsed_ms(r[1], r[2])
         for k_, (c_, f_, m_) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
             log(f'conv {str(k_):100s} x{c_:4d}  {m_ / reps:7.3f} ms/step  {f_ / m_ / 1e9:7.1f} TFLOP/s')
+    if a.conv_sequence:                     # the conv launches of ONE step in launch order: tools/pmc_traffic.py lines the PMC
+        per_step = len(rec) // reps         # dispatches of the same command up against it (per-shape HBM bytes vs algorithmic)
+        with open(a.conv_sequence, 'w') as f:
+            json.dump({'launches_per_step': per_step, 'workload': a.workload, 'dtype': dtype_name, 'candidates': a.candidates,
+                       'sequence': [{'shape': str(r[3]), 'kernel': r[5], 'alg_bytes': r[4], 'flop': r[0],
+                                     'us': round(hev.elapsed_ms(r[1], r[2]) * 1e3, 2)} for r in rec[:per_step]]}, f)
     ach = fl / (ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[dtype_name]
     per_kernel = {}
@@ -405,20 +413,33 @@ def parity_leg(job, orc, nets):
                      'index_equal': bool(int(sc.argmax()) == orc['best'])}
     steps_i = [2, 3, 5, 7, 9, 11, 13, 14]
     agree = {name: 0 for name in nets if name != 'f32'}
+    dev_max = {name: 0.0 for name in agree}                   # largest |reward - f32 reward| over all candidates and iterations
+    regret = {name: [] for name in agree}                     # f32 reward given up by each differing pick (0 = same candidate)
     gaps = []
     for r, i_step in enumerate(steps_i):
-        best = {}
+        best, scores = {}, {}
         for name, (net, scorer) in nets.items():               # same seed => the same state, pivot and candidate set for every dtype
             it = EpsGreedyIteration(job, net, scorer, n, i_step=i_step, sets=1, seed=4321 + r)
             best[name] = it(0)
+            scores[name] = it.last_scores.flatten().double().cpu()
             if name == 'f32':
-                s = torch.sort(it.last_scores.flatten(), descending=True).values
+                s = torch.sort(scores[name], descending=True).values
                 gaps.append(float(s[0] - s[1]))
         for name in agree:
             agree[name] += int(best[name] == best['f32'])
+            dev_max[name] = max(dev_max[name], float((scores[name] - scores['f32']).abs().max()))
+            regret[name].append(float(f"{float(scores['f32'][best['f32']] - scores['f32'][best[name]]):.3e}"))
+    # a pick can only be expected to survive a change of arithmetic when the f32 top-2 gap exceeds the mode's own reward noise:
+    # `decidable` counts those iterations (gap > 2 x the mode's largest reward deviation) and how many of them agree
+    decidable = {}
+    for name in agree:
+        idx = [k for k, g_ in enumerate(gaps) if g_ > 2 * dev_max[name]]
+        decidable[name] = f"{sum(1 for k in idx if regret[name][k] == 0.0)}/{len(idx)}"
     out['index_agreement'] = {'reference': 'GPU f32 parity mode (checked against the oracle above)', 'iterations': len(steps_i),
                               'sigma_steps': steps_i, 'f32_top2_gaps': [float(f'{g_:.3e}') for g_ in gaps],
-                              **{name: f'{v}/{len(steps_i)}' for name, v in agree.items()}}
+                              **{name: f'{v}/{len(steps_i)}' for name, v in agree.items()},
+                              'max_reward_dev_vs_f32': {k_: float(f'{v:.3e}') for k_, v in dev_max.items()},
+                              'f32_reward_given_up': regret, 'agree_where_gap_exceeds_2x_dev': decidable}
     return out
 
 

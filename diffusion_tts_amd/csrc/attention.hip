@@ -23,12 +23,14 @@ template <> struct AttMma<bf16_t> {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
   }
   static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack2_bf16(lo, hi); }
+  static constexpr uint32_t ONES2 = 0x3F803F80u;            // two 1.0
 };
 template <> struct AttMma<f16_t> {
   static __device__ __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
   }
   static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack2_f16(lo, hi); }
+  static constexpr uint32_t ONES2 = 0x3C003C00u;
 };
 
 struct AttP {
@@ -63,8 +65,12 @@ __device__ __forceinline__ void att_block(const AttP& p, int& nh, int& qb) {
 // slice vs = slot % (D/DV)): the 128 accumulator registers a 512-wide output would need do not fit beside the 64 of the query
 // fragments.  Q.K^T is recomputed per slice (1.5x the FLOPs of the unsplit product); the K/V tiles then go to LDS without the
 // register prefetch (PREF = false: 96 more registers).
-template <typename T, int D, int QT, int DV = D, bool PREF = true>
+// DB (with PREF): the K/V tiles alternate between two LDS buffers, so a key tile costs ONE block barrier: tile k+1 is written to
+// the other buffer while tile k is still being read (the barrier at the top of the next trip publishes it), and the global
+// loads of tile k+2 go out right behind.  Available where two buffers still leave >= 2 blocks per CU (head dims 64 and 128).
+template <typename T, int D, int QT, int DV = D, bool PREF = true, bool DB = false>
 __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
+  static_assert(!DB || PREF, "double buffering rides on the register prefetch");
   constexpr int ES = 2, ROWB = D * ES + 32;        // LDS row stride of K in bytes
   constexpr int VROWB = DV * ES + 32;              // LDS row stride of the V slice
   constexpr int CH = D / 8;                        // 16-byte chunks per K row
@@ -73,6 +79,7 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
   constexpr int DT = DV / 16;                      // output d tiles
   constexpr int NSL = D / DV;                      // value slices
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BUFB = 64 * ROWB + 64 * VROWB;      // one K + V tile
   char* sK = smem;
   char* sV = smem + 64 * ROWB;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -101,10 +108,16 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
   // powers of two (d = 64, 256: scale = 1/8, 1/16) the product q*scale is exact in bf16/f16; log2e is applied in f32 below.
   const float sc2 = p.scale_log2e;
   f32x4_t o[QT][DT];
-  float m_run[QT], l_run[QT];
+  // The softmax denominator comes off the matrix core too: an all-ones A operand against P^T gives, in every row of a 16x16 tile,
+  // the sum over the 32 keys of the k-step, i.e. l accumulates exactly like O (same rounded P, rescaled by the same alpha) and
+  // the 16 adds + 2 cross-lane shuffles per query tile and key tile leave the VALU, which is this kernel's bound at d = 64
+  // (~7 VALU issue slots per S element against 4 MFMAs per 16x16 S tile).
+  f32x4_t ol[QT];
+  const uint4 ones = make_uint4(AttMma<T>::ONES2, AttMma<T>::ONES2, AttMma<T>::ONES2, AttMma<T>::ONES2);
+  float m_run[QT];
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
-    m_run[qt] = -INFINITY; l_run[qt] = 0.f;
+    m_run[qt] = -INFINITY; ol[qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < DT; ++i) o[qt][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
@@ -127,21 +140,31 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
     pv[u] = make_uint4(0, 0, 0, 0);                                                               \
     if ((key0_) + r < p.t) pv[u] = *reinterpret_cast<const uint4*>(vbase + (size_t)((key0_) + r) * rowstride + c * 16); \
   }
+#define ATT_STAGE_TILE(boff_)                                                                     \
+  _Pragma("unroll") for (int u = 0; u < NCH; ++u) {                                               \
+    const int idx = tid + 256 * u, r = idx / CH, c = idx - r * CH;                                \
+    *reinterpret_cast<uint4*>(sK + (boff_) + r * ROWB + c * 16) = pk[u];                          \
+  }                                                                                               \
+  _Pragma("unroll") for (int u = 0; u < NCHV; ++u) {                                              \
+    const int idx = tid + 256 * u, r = idx / CHV, c = idx - r * CHV;                              \
+    *reinterpret_cast<uint4*>(sV + (boff_) + r * VROWB + c * 16) = pv[u];                         \
+  }
   if constexpr (PREF) { ATT_LOAD_TILE(0); }
+  if constexpr (DB) {                                // tile 0 -> buffer 0, tile 1 on its way
+    ATT_STAGE_TILE(0);
+    if (ntiles > 1) { ATT_LOAD_TILE(64); }
+  }
   for (int kt = 0; kt < ntiles; ++kt) {
     const int key0 = kt * 64;
-    __syncthreads();                                 // previous tile fully consumed
-    if constexpr (PREF) {
-#pragma unroll
-      for (int u = 0; u < NCH; ++u) {
-        const int idx = tid + 256 * u, r = idx / CH, c = idx - r * CH;
-        *reinterpret_cast<uint4*>(sK + r * ROWB + c * 16) = pk[u];
+    const int boff = DB ? (kt & 1) * BUFB : 0;       // this tile's buffer
+    __syncthreads();                                 // DB: tile kt published, tile kt-1 fully consumed; else: previous tile consumed
+    if constexpr (DB) {
+      if (kt + 1 < ntiles) {
+        ATT_STAGE_TILE(BUFB - boff);                 // tile kt+1 into the buffer tile kt-1 occupied
+        if (kt + 2 < ntiles) { ATT_LOAD_TILE(key0 + 128); }
       }
-#pragma unroll
-      for (int u = 0; u < NCHV; ++u) {
-        const int idx = tid + 256 * u, r = idx / CHV, c = idx - r * CHV;
-        *reinterpret_cast<uint4*>(sV + r * VROWB + c * 16) = pv[u];
-      }
+    } else if constexpr (PREF) {
+      ATT_STAGE_TILE(0);
     } else {
       // no register prefetch: global -> LDS in groups of four chunks (the loads of a group are in flight together)
 #pragma unroll
@@ -175,8 +198,10 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
         }
       }
     }
-    __syncthreads();
-    if constexpr (PREF) { if (kt + 1 < ntiles) { ATT_LOAD_TILE(key0 + 64); } }
+    if constexpr (!DB) {
+      __syncthreads();
+      if constexpr (PREF) { if (kt + 1 < ntiles) { ATT_LOAD_TILE(key0 + 64); } }
+    }
 
     // ---- S^T tiles: 4 x (16 keys x 16 queries) per query tile; a K fragment feeds every query tile
     f32x4_t sacc[QT][4];
@@ -186,7 +211,7 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
       for (int qt = 0; qt < QT; ++qt) sacc[qt][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < KSTEPS; ++s) {
-        const uint4 ka = *reinterpret_cast<const uint4*>(sK + (j * 16 + lq) * ROWB + (lg + 4 * s) * 16);
+        const uint4 ka = *reinterpret_cast<const uint4*>(sK + boff + (j * 16 + lq) * ROWB + (lg + 4 * s) * 16);
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) sacc[qt][j] = AttMma<T>::run(ka, qf[qt][s], sacc[qt][j]);
       }
@@ -212,22 +237,15 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
       const float m_new = fmaxf(m_run[qt], tmax);    // finite: every tile has >= 1 valid key
       const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * sc2);
       const float mb = m_new * sc2;
-      float psum = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(fmaf(sacc[qt][j][r], sc2, -mb));
-          sacc[qt][j][r] = e;
-          psum += e;
-        }
-      psum += __shfl_xor(psum, 16, 64);
-      psum += __shfl_xor(psum, 32, 64);
-      l_run[qt] = l_run[qt] * alpha + psum;
+        for (int r = 0; r < 4; ++r) sacc[qt][j][r] = __builtin_amdgcn_exp2f(fmaf(sacc[qt][j][r], sc2, -mb));
       m_run[qt] = m_new;
       if (!__all(alpha == 1.0f)) {                   // running max unchanged for the whole wave: nothing to rescale
 #pragma unroll
         for (int i = 0; i < DT; ++i) o[qt][i] *= alpha;
+        ol[qt][0] *= alpha;                          // rows of the ones-tile are all equal; only element 0 is read
       }
       // P^T as the B operand; k-slot (lg, e): e<4 -> key 16*(2kk) + 4lg + e ; e>=4 -> key 16*(2kk+1) + 4lg + e-4
 #pragma unroll
@@ -244,7 +262,9 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
     for (int kk = 0; kk < 2; ++kk) {
       // transposed read: lane 4q'+p' of each 16-lane group addresses row q', columns 4p'..4p'+3 of a 4x16 block
       const int rq = (lane & 15) >> 2, rp = lane & 3;
-      const char* va = sV + (32 * kk + 4 * lg + rq) * VROWB + rp * 8;
+      const char* va = sV + boff + (32 * kk + 4 * lg + rq) * VROWB + rp * 8;
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) ol[qt] = AttMma<T>::run(ones, pb[qt][kk], ol[qt]);
       const char* vb = va + 16 * VROWB;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
@@ -263,7 +283,7 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
   for (int qt = 0; qt < QT; ++qt) {
     const int qrow = q0 + qt * 16 + lq;
     if (qrow < p.t) {
-      const float inv = 1.f / l_run[qt];
+      const float inv = 1.f / ol[qt][0];
       T* orow = reinterpret_cast<T*>(p.out) + ((size_t)n * p.t + qrow) * C + head * D + vs * DV;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
@@ -273,6 +293,7 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
   }
 }
 #undef ATT_LOAD_TILE
+#undef ATT_STAGE_TILE
 
 // ------------------------------------------------------------------------------------------------
 // f32 (parity) path: same structure on v_mfma_f32_16x16x4_f32; V needs no transpose (one k per lane group).
@@ -411,13 +432,18 @@ template <typename T>
 int att16(const AttP& p, hipStream_t st) {
   const int g_att_qt = dts_knob_get(DTS_KNOB_ATT_QT) > 0 ? dts_knob_get(DTS_KNOB_ATT_QT) : 0;    // DTS_ATT_QT=1|2 forces the query tiles per wave
   const size_t lds = (size_t)2 * 64 * (p.d * 2 + 32);
+  // double-buffered tiles measured no faster (T=1024: 167.6 vs 166.3 us; T=256: 27.0 vs 25.7 us, profiles/r02_attention_variants.txt):
+  // the barrier was not what the waves wait on.  Kept behind DTS_ATT_DB=1 for the record; default single-buffered.
+  const bool db = dts_knob_get(DTS_KNOB_ATT_DB) == 1 && p.t > 64;
   switch (p.d) {
     case 64:
       // two query tiles per wave once the sequence is long enough to keep >= 2 blocks per CU in the grid
       if (g_att_qt == 2 || (g_att_qt == 0 && p.t >= 256 && (long long)((p.t + 127) / 128) * p.n * p.heads >= 512))
-        return launch_att(attention16_kernel<T, 64, 2>, p, lds, st, 128);
-      return launch_att(attention16_kernel<T, 64, 1>, p, lds, st);
-    case 128: return launch_att(attention16_kernel<T, 128, 1>, p, lds, st);
+        return db ? launch_att(attention16_kernel<T, 64, 2, 64, true, true>, p, 2 * lds, st, 128)
+                  : launch_att(attention16_kernel<T, 64, 2>, p, lds, st, 128);
+      return db ? launch_att(attention16_kernel<T, 64, 1, 64, true, true>, p, 2 * lds, st) : launch_att(attention16_kernel<T, 64, 1>, p, lds, st);
+    case 128:
+      return db ? launch_att(attention16_kernel<T, 128, 1, 128, true, true>, p, 2 * lds, st) : launch_att(attention16_kernel<T, 128, 1>, p, lds, st);
     case 256: return launch_att(attention16_kernel<T, 256, 1>, p, lds, st);
     case 512:   // two 256-wide value slices per (sample, head, query block); K rows 1056 B + V-slice rows 544 B per key
       return launch_att(attention16_kernel<T, 512, 1, 256, false>, p, (size_t)64 * (512 * 2 + 32) + (size_t)64 * (256 * 2 + 32), st, 64, 2);

@@ -3,6 +3,7 @@
 //   dts_conv_in3 : edm/training/networks.py:410 (enc '<res>x<res>_conv'), :284 (SongUNet), edm/unet.py:757
 //   dts_conv_out3: edm/training/networks.py:433,460 (out_conv), :318,357 (SongUNet aux_conv)
 #include "dts_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -78,6 +79,81 @@ __global__ __launch_bounds__(256) void conv_in3_kernel(const float* __restrict__
   }
 }
 
+// The same convolution on the f32 matrix cores for 16-bit outputs at sizes the U-Nets use (w % 16 == 0, cout = 16*NT): the direct
+// kernel above is VALU-bound (27*cout f32 FMAs per pixel: 161 us for 128 x 64 x 64 x 192 against a 40 us output write).  K = 27
+// taps padded to 28 = 7 steps of v_mfma_f32_16x16x4_f32, an exact f32 FMA chain like the direct kernel's, on the unrounded f32
+// input and weights.  A wave owns 16 consecutive pixels of one image row: A = the weights (kept in registers for the wave's
+// whole life, 7 per 16-cout tile), B = the 28 x 16 im2col values (7 gathered loads from the NCHW planes), and a lane's four
+// accumulators are four consecutive couts of one pixel.  The 16 x cout tile goes through a wave-private LDS slab (rows padded
+// by 16 B) and leaves as ONE contiguous 32*cout-byte NHWC segment, 16 bytes per lane.
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void conv_in3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, T* __restrict__ out, int nseg, int h,
+                                                             int wd) {
+  constexpr int COUT = NT * 16, ROWB = COUT * 2 + 16, TG = 4;           // TG independent accumulator tiles in flight
+  static_assert(NT % TG == 0, "tile groups");
+  __shared__ __attribute__((aligned(16))) char stage_all[4 * 16 * ROWB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, kq = lane >> 4;
+  char* stage = stage_all + wave * 16 * ROWB;
+  float a[NT][7];
+  int dci[7], dy[7], dx[7];
+#pragma unroll
+  for (int s = 0; s < 7; ++s) {
+    const int k = 4 * s + kq;
+    const int kk = k < 27 ? k : 0;
+    dci[s] = k < 27 ? kk / 9 : -1;
+    dy[s] = (kk % 9) / 3 - 1;
+    dx[s] = kk % 3 - 1;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) a[t][s] = k < 27 ? w[(16 * t + p) * 27 + k] : 0.f;
+  }
+  f32x4_t b0[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const float4 q = bias ? *reinterpret_cast<const float4*>(bias + 16 * t + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    b0[t][0] = q.x; b0[t][1] = q.y; b0[t][2] = q.z; b0[t][3] = q.w;
+  }
+  const int spr = wd >> 4;
+  const size_t plane = (size_t)h * wd;
+  for (int seg = blockIdx.x * 4 + wave; seg < nseg; seg += gridDim.x * 4) {
+    const int xs = seg % spr, rest = seg / spr;
+    const int y = rest % h, n = rest / h;
+    float bv[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+      const int yy = y + dy[s], xx = xs * 16 + p + dx[s];
+      const bool ok = dci[s] >= 0 && (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)wd;
+      const size_t idx = ok ? ((size_t)n * 3 + dci[s]) * plane + (size_t)yy * wd + xx : 0;
+      const float v = x[idx];
+      bv[s] = ok ? v : 0.f;
+    }
+#pragma unroll
+    for (int t0 = 0; t0 < NT; t0 += TG) {
+      f32x4_t acc[TG];
+#pragma unroll
+      for (int u = 0; u < TG; ++u) acc[u] = b0[t0 + u];
+#pragma unroll
+      for (int s = 0; s < 7; ++s)
+#pragma unroll
+        for (int u = 0; u < TG; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t0 + u][s], bv[s], acc[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < TG; ++u) {
+        uint2 o;
+        if (std::is_same<T, bf16_t>::value) { o.x = pack2_bf16(acc[u][0], acc[u][1]); o.y = pack2_bf16(acc[u][2], acc[u][3]); }
+        else { o.x = pack2_f16(acc[u][0], acc[u][1]); o.y = pack2_f16(acc[u][2], acc[u][3]); }
+        *reinterpret_cast<uint2*>(stage + p * ROWB + (16 * (t0 + u) + 4 * kq) * 2) = o;
+      }
+    }
+    // the slab is wave-private and a wave's LDS operations complete in order: no barrier
+    char* dst = reinterpret_cast<char*>(out + (size_t)seg * 16 * COUT);
+#pragma unroll
+    for (int c = lane; c < 2 * COUT; c += 64) {
+      const int px = c / (COUT / 8), ch = c - px * (COUT / 8);
+      *reinterpret_cast<uint4*>(dst + (size_t)c * 16) = *reinterpret_cast<const uint4*>(stage + px * ROWB + ch * 16);
+    }
+  }
+}
+
 // x NHWC T [n][h][w][c]; w f32 [3][3][3][c] (O, kh, kw, I); out f32 NCHW [n][3][h][w]
 // 4 lanes per output pixel split the channel chunks; xor-shuffle reduce.
 template <typename T>
@@ -142,6 +218,23 @@ extern "C" int dts_conv_in3(const float* x, const float* w, const float* bias, v
   DTS_CHECK_ARG(x && w && out, "dts_conv_in3: null pointer");
   DTS_CHECK_ARG(n > 0 && h > 0 && w_ > 0 && cout % 8 == 0 && cout <= 512, "dts_conv_in3: bad shape (cout=%d)", cout);
   hipStream_t st = to_stream(s);
+  const long long nseg = (long long)n * h * (w_ / 16);
+  if (dtype != DTS_F32 && w_ % 16 == 0 && (cout == 192 || cout == 128 || cout == 64) && nseg < (1ll << 31) &&
+      (bias == nullptr || ((uintptr_t)bias & 15) == 0)) {
+    long long g = (nseg + 31) / 32;                      // 8 segments per wave: the 7*NT weight registers are loaded once per wave
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;
+#define DTS_IN3_MFMA(TT, NT_)                                                                                                    \
+  hipLaunchKernelGGL((conv_in3_mfma_kernel<TT, NT_>), dim3((int)g), dim3(256), 0, st, x, w, bias, (TT*)out, (int)nseg, h, w_)
+    if (dtype == DTS_BF16) {
+      if (cout == 192) DTS_IN3_MFMA(bf16_t, 12); else if (cout == 128) DTS_IN3_MFMA(bf16_t, 8); else DTS_IN3_MFMA(bf16_t, 4);
+    } else {
+      if (cout == 192) DTS_IN3_MFMA(f16_t, 12); else if (cout == 128) DTS_IN3_MFMA(f16_t, 8); else DTS_IN3_MFMA(f16_t, 4);
+    }
+#undef DTS_IN3_MFMA
+    DTS_CHECK_LAUNCH("dts_conv_in3");
+    return DTS_OK;
+  }
   DTS_DISPATCH_DTYPE(dtype, {
     const long long total = (long long)n * h * w_;
     long long g = (total + 255) / 256;

@@ -104,12 +104,34 @@ __global__ __launch_bounds__(64) void gn_coef_strips_kernel(const float* __restr
   const int C = c1 + c2, cg = C / groups, g = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
   double a = 0.0, b = 0.0;
   const int total = strips * cg;
-  for (int e = lane; e < total; e += 64) {
-    const int s = e / cg, c = g * cg + (e - s * cg);
-    const float* src; int cs, co;
-    if (c < c1) { src = st1; cs = c1; co = c; } else { src = st2; cs = c2; co = c - c1; }
-    const float2 q = *reinterpret_cast<const float2*>(src + (((size_t)n * strips + s) * cs + co) * 2);
-    a += q.x; b += q.y;
+  const float inv_cg = 1.0f / (float)cg;
+  // the affine / adaptive parameters do not depend on the sums: fetch them first so their latency hides under the strip loads
+  float pg[2], pb[2], psc[2], psh[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int ch = lane + 64 * u, c = g * cg + ch;
+    const bool ok = ch < cg;
+    pg[u] = (ok && gamma) ? gamma[c] : 1.f;
+    pb[u] = (ok && beta) ? beta[c] : 0.f;
+    psc[u] = (ok && ss) ? ld1<T>(ss + (size_t)n * ld_ss + c) : 0.f;
+    psh[u] = (ok && ss) ? ld1<T>(ss + (size_t)n * ld_ss + C + c) : 0.f;
+  }
+  // eight independent loads per trip: the kernel is one dependent-latency chain per trip, so the trip count is its run time
+  for (int e0 = lane; e0 < total; e0 += 64 * 8) {
+    float2 q[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + 64 * u;
+      q[u] = make_float2(0.f, 0.f);
+      if (e < total) {
+        const int s = (int)(((float)e + 0.5f) * inv_cg), c = g * cg + (e - s * cg);       // exact for e < 2^22
+        const float* src; int cs, co;
+        if (c < c1) { src = st1; cs = c1; co = c; } else { src = st2; cs = c2; co = c - c1; }
+        q[u] = *reinterpret_cast<const float2*>(src + (((size_t)n * strips + s) * cs + co) * 2);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a += q[u].x; b += q[u].y; }
   }
   a = wave_sum(a);
   b = wave_sum(b);
@@ -119,18 +141,18 @@ __global__ __launch_bounds__(64) void gn_coef_strips_kernel(const float* __restr
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
   const float fm = (float)mean;
-  for (int ch = lane; ch < cg; ch += 64) {
-    const int c = g * cg + ch;
-    float A = rstd * (gamma ? gamma[c] : 1.f);
-    float B = (beta ? beta[c] : 0.f) - fm * A;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int ch = lane + 64 * u, c = g * cg + ch;
+    if (ch >= cg) break;
+    float A = rstd * pg[u];
+    float B = pb[u] - fm * A;
     if (ss) {
-      const float sc = 1.f + ld1<T>(ss + (size_t)n * ld_ss + c);
-      const float sh = ld1<T>(ss + (size_t)n * ld_ss + C + c);
+      const float sc = 1.f + psc[u];
       A = A * sc;
-      B = B * sc + sh;
+      B = B * sc + psh[u];
     }
-    coef[((size_t)n * C + c) * 2 + 0] = A;
-    coef[((size_t)n * C + c) * 2 + 1] = B;
+    *reinterpret_cast<float2*>(coef + ((size_t)n * C + c) * 2) = make_float2(A, B);
   }
 }
 
@@ -403,6 +425,7 @@ extern "C" int dts_gn_coef_strips(const float* st1, int c1, const float* st2, in
   DTS_CHECK_ARG(n > 0 && hw > 0 && hw % 64 == 0 && groups > 0 && C % groups == 0, "dts_gn_coef_strips: hw=%d C=%d groups=%d", hw, C,
                 groups);
   DTS_CHECK_ARG(c2 == 0 || st2, "dts_gn_coef_strips: c2 without st2");
+  DTS_CHECK_ARG(C / groups <= 128, "dts_gn_coef_strips: %d channels per group (max 128)", C / groups);
   DTS_CHECK_ARG(scale_shift == nullptr || ld_ss >= 2 * C, "dts_gn_coef_strips: ld_ss=%d < 2*C=%d", ld_ss, 2 * C);
   DTS_CHECK_ARG(n <= 65535, "dts_gn_coef_strips: n too large for grid.y");
   hipStream_t st = to_stream(s);

@@ -34,6 +34,43 @@ class VAEDecoder:
         self.decodes = 0
         self._load(state_dict)
 
+    @classmethod
+    def from_pretrained(cls, path, device='cuda', dtype=torch.float16):
+        """Reads a diffusers `vae/` directory (or a single `.safetensors` file): `config.json` for the shape and
+        `diffusion_pytorch_model[.fp16].safetensors` for the parameters -- the on-disk format of SD-1.5's VAE.
+        Only the decoder half (`decoder.*`, `post_quant_conv.*`) is read; tensors are loaded lazily, so the encoder never leaves disk."""
+        import json
+        import os
+        from safetensors import safe_open
+        cfg = {}
+        if os.path.isdir(path):
+            cfg_file = os.path.join(path, 'config.json')
+            if os.path.exists(cfg_file):
+                with open(cfg_file) as f:
+                    cfg = json.load(f)
+            names = [n for n in ('diffusion_pytorch_model.safetensors', 'diffusion_pytorch_model.fp16.safetensors') if
+                     os.path.exists(os.path.join(path, n))]
+            if not names:
+                raise FileNotFoundError(f'{path}: no diffusion_pytorch_model[.fp16].safetensors (a .bin pickle is not read: convert it to safetensors)')
+            path = os.path.join(path, names[0])
+        for key, want in (('act_fn', 'silu'), ('_class_name', 'AutoencoderKL')):
+            if key in cfg and cfg[key] != want:
+                raise ValueError(f'VAEDecoder: {key}={cfg[key]!r} is not the stock SD VAE ({want!r})')
+        for t in cfg.get('up_block_types', []):
+            if t != 'UpDecoderBlock2D':
+                raise ValueError(f'VAEDecoder: up block {t!r} unsupported')
+        sd = {}
+        with safe_open(path, framework='pt', device='cpu') as f:
+            for k in f.keys():
+                if k.startswith('decoder.') or k.startswith('post_quant_conv.'):
+                    sd[k] = f.get_tensor(k)
+        if not sd:
+            raise ValueError(f'{path}: no decoder.* tensors')
+        kw = {k: cfg[k] for k in ('layers_per_block', 'latent_channels', 'norm_num_groups', 'scaling_factor') if k in cfg}
+        if 'block_out_channels' in cfg:
+            kw['block_out_channels'] = tuple(cfg['block_out_channels'])
+        return cls(sd, device=device, dtype=dtype, **kw)
+
     # ------------------------------------------------------------------------------------------
     def _f(self, t):
         return t.detach().to(self.device, torch.float32).contiguous()

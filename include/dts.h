@@ -36,7 +36,7 @@ enum dts_status { DTS_OK = 0, DTS_ERR_ARG = -1, DTS_ERR_LAUNCH = -2, DTS_ERR_UNS
 int dts_version(void);            /* == DTS_ABI_VERSION of the build; a binding must refuse any other value */
 const char* dts_last_error(void);
 /* Tuning knobs (measurement aid; a knob only selects between kernels / block orders with identical results).  knob: index of
- * enum dts_knob in csrc/dts_common.h; value -1 = launcher default.  Used by tools/*_bench.py to A/B variants in one process. */
+ * enum dts_knob in csrc/dts_common.h; value -1 = launcher default.  Used by tools/conv_bench.py and tools/att_bench.py to A/B variants in one process. */
 int dts_set_tuning(int knob, int value);
 int dts_get_tuning(int knob);
 

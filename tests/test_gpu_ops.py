@@ -219,6 +219,25 @@ def test_conv_in3_out3(ops, dtype):
     assert rel_err(got, onet.conv2d(y, w3, b3)) < 1e-5
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('cout,res,n', [(192, 64, 3), (128, 32, 5), (64, 48, 2), (192, 24, 2)])
+def test_conv_in3_matrix_core_path(ops, dtype, cout, res, n):
+    """First conv at the U-Nets' shapes (networks.py:410 ADM 3->192 at 64x64, :284 DDPM++ 3->128 at 32x32): the f32-MFMA kernel keeps
+    the f32 input and weights exact, so it must agree with the direct f32 kernel to the output rounding; res=24 (not a multiple
+    of 16) takes the direct kernel."""
+    gen = g(33)
+    x = torch.randn(n, 3, res, res, generator=gen) * 3
+    w = torch.randn(cout, 3, 3, 3, generator=gen) / 5
+    b = torch.randn(cout, generator=gen)
+    got = from_nhwc(ops, ops.conv_in3(x.to(DEV), w.to(DEV), b.to(DEV), cout, dtype))
+    exact = from_nhwc(ops, ops.conv_in3(x.to(DEV), w.to(DEV), b.to(DEV), cout, torch.float32))
+    assert rel_err(exact, onet.conv2d(x, w, b)) < 1e-5
+    assert torch.equal(got, q(exact, dtype)) or (got - q(exact, dtype)).abs().max() <= 2 * (exact.abs().max() * 2.0 ** -8)
+    assert rel_err(got, exact) < TOL[dtype]
+    nb = from_nhwc(ops, ops.conv_in3(x.to(DEV), w.to(DEV), None, cout, dtype))
+    assert rel_err(nb, onet.conv2d(x, w, None)) < TOL[dtype]
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('path', ['fused', 'split'])
 @pytest.mark.parametrize('variant', ['plain', 'adaptive', 'pool', 'cat', 'nosilu'])

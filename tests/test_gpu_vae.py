@@ -78,3 +78,35 @@ def test_sd_search_loop_with_the_hip_vae_at_sd_shapes():
     got = out.images.float().cpu()
     want = (want / 2 + 0.5).clamp(0, 1)
     assert (got - want).abs().max().item() < 3e-2
+
+
+def test_vae_decoder_from_a_diffusers_directory(tmp_path, vg):
+    """Weight ingestion (SD side): a diffusers `vae/` directory -- config.json + diffusion_pytorch_model.safetensors,
+    encoder tensors included -- loads into the same decoder as the state dict does (bit-identical images), and a directory without
+    safetensors is refused rather than un-pickled."""
+    import json
+    from safetensors.torch import save_file
+    from diffusion_tts_amd.vae import VAEDecoder
+    boc = (64, 64, 128, 128)
+    sd = dinit.vae_decoder_state_dict(boc, 2, 4, seed=3)
+    d = tmp_path / 'vae'
+    d.mkdir()
+    full = {k: v.to(torch.float16).contiguous() for k, v in sd.items()}
+    full['encoder.conv_in.weight'] = torch.zeros(8, 3, 3, 3, dtype=torch.float16)          # must be skipped
+    save_file(full, str(d / 'diffusion_pytorch_model.safetensors'))
+    (d / 'config.json').write_text(json.dumps({'_class_name': 'AutoencoderKL', 'act_fn': 'silu', 'block_out_channels': list(boc),
+                                               'layers_per_block': 2, 'latent_channels': 4, 'norm_num_groups': 32, 'scaling_factor': 0.18215,
+                                               'up_block_types': ['UpDecoderBlock2D'] * 4}))
+    a = VAEDecoder.from_pretrained(str(d), device=DEV, dtype=torch.float16)
+    b = VAEDecoder({k: v.float() for k, v in full.items() if not k.startswith('encoder.')}, block_out_channels=boc, device=DEV, dtype=torch.float16)
+    z = torch.from_numpy(vg['narrow_z']).to(DEV)
+    assert torch.equal(a.decode(z, return_dict=False)[0], b.decode(z, return_dict=False)[0])
+    assert a.config.block_out_channels == list(boc) and a.config.scaling_factor == 0.18215
+    empty = tmp_path / 'empty'
+    empty.mkdir()
+    (empty / 'diffusion_pytorch_model.bin').write_bytes(b'x')
+    with pytest.raises(FileNotFoundError):
+        VAEDecoder.from_pretrained(str(empty))
+    (d / 'config.json').write_text(json.dumps({'act_fn': 'relu'}))
+    with pytest.raises(ValueError):
+        VAEDecoder.from_pretrained(str(d))

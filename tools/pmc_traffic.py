@@ -3,7 +3,7 @@
 per launch per kernel, with the corrections MI355X_MICROARCH.md prescribes: both counters are in KiB... (units stated in the
 output), and gfx950 reports half the bytes of wide coalesced reads, hence fetch x2.
 
-    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_hbm_traffic_pmc.json
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r02_hbm_traffic_pmc.json [conv_sequence.json]
 """
 import collections
 import csv
@@ -27,12 +27,63 @@ def per_kernel(directory, counter):
     return tot, cnt
 
 
+def conv_dispatches(directory, counter):
+    """(kernel family, value) of every conv dispatch in dispatch order."""
+    out = []
+    for f in glob.glob(os.path.join(directory, '**', '*counter_collection.csv'), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r['Counter_Name'] != counter:
+                continue
+            n = short(r['Kernel_Name'])
+            if n.startswith('conv_pp_kernel') or n.startswith('conv_igemm_kernel'):
+                fam = n.split('<')[0]
+                if fam == 'conv_igemm_kernel':
+                    fam += '/3x3' if n.endswith('true>') else '/1x1'
+                out.append((int(r['Dispatch_Id']), fam, float(r['Counter_Value'])))
+    out.sort()
+    return [(k, v) for _, k, v in out]
+
+
+def per_shape(fetch_dir, write_dir, seq_file):
+    """Per conv shape: PMC bytes per launch next to the algorithmic bytes.  The conv launches of a step are a fixed sequence
+    (bench.py --conv-sequence wrote it from the same command), so dispatch i of the trace is entry i mod len(sequence)."""
+    seq = json.load(open(seq_file))['sequence']
+    fd, wd = conv_dispatches(fetch_dir, 'FETCH_SIZE'), conv_dispatches(write_dir, 'WRITE_SIZE')
+    L = len(seq)
+    if not fd or len(fd) % L or len(wd) % L:
+        return {'error': f'{len(fd)} / {len(wd)} conv dispatches are not a multiple of the {L}-launch step sequence'}
+    bad = sum(1 for i, (k, _) in enumerate(fd) if k != seq[i % L]['kernel'])
+    if bad:
+        return {'error': f'{bad} dispatches run a different kernel than the logged sequence says'}
+    agg = collections.OrderedDict()
+    for which, d in (('fetch', fd), ('write', wd)):
+        for i, (_, v) in enumerate(d):
+            e = seq[i % L]
+            t = agg.setdefault((e['shape'], e['kernel']), {'launches_per_step': 0, 'alg_bytes': e['alg_bytes'], 'flop': e['flop'], 'us': 0.0,
+                                                           'fetch': 0.0, 'write': 0.0, 'nf': 0, 'nw': 0})
+            t[which] += v * 1024
+            t['nf' if which == 'fetch' else 'nw'] += 1
+    for i, e in enumerate(seq):
+        t = agg[(e['shape'], e['kernel'])]
+        t['launches_per_step'] += 1
+        t['us'] += e['us']
+    rows = []
+    for (shape, kern), t in agg.items():
+        hbm = 2 * t['fetch'] / t['nf'] + t['write'] / t['nw']
+        rows.append({'shape': shape, 'kernel': kern, 'launches_per_step': t['launches_per_step'], 'avg_us': round(t['us'] / t['launches_per_step'], 1),
+                     'alg_mb': round(t['alg_bytes'] / 1e6, 1), 'pmc_mb': round(hbm / 1e6, 1), 'pmc_over_alg': round(hbm / t['alg_bytes'], 2),
+                     'tflops': round(t['flop'] * t['launches_per_step'] / t['us'] / 1e6, 1)})
+    rows.sort(key=lambda r: -r['avg_us'] * r['launches_per_step'])
+    return {'rows': rows}
+
+
 def short(name):
     return name.replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', '').split('(')[0]
 
 
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
+    seq_file = sys.argv[4] if len(sys.argv) > 4 else None
     ft, fc = per_kernel(fetch_dir, 'FETCH_SIZE')
     wt, wc = per_kernel(write_dir, 'WRITE_SIZE')
     kernels = {}
@@ -45,8 +96,14 @@ def main():
                              'write_size_bytes_per_launch': write, 'hbm_bytes_per_launch': 2 * fetch + write}
     # per conv kernel family (the name bench.py's roofline.kernel uses), launch-weighted over its template instantiations
     fam = {}
-    for famname in ('conv_pp_kernel', 'conv_igemm_kernel'):
-        ks = [v for k, v in kernels.items() if k.startswith(famname)]
+    # families as bench.py names them: the ping-pong / halo kernel, and the 4-wave kernel's 3x3 (fragment-prefetch instantiation,
+    # last template argument true) and 1x1 launches
+    pick = {'conv_pp_kernel': lambda k: k.startswith('conv_pp_kernel'),
+            'conv_igemm_kernel/3x3': lambda k: k.startswith('conv_igemm_kernel') and k.endswith('true>'),
+            'conv_igemm_kernel/1x1': lambda k: k.startswith('conv_igemm_kernel') and k.endswith('false>'),
+            'conv_igemm_kernel': lambda k: k.startswith('conv_igemm_kernel')}
+    for famname, f_ in pick.items():
+        ks = [v for k, v in kernels.items() if f_(k)]
         nl = sum(v['launches'] for v in ks)
         if nl:
             fam[famname] = {'launches': nl, 'hbm_bytes_per_launch': sum(v['hbm_bytes_per_launch'] * v['launches'] for v in ks) / nl}
@@ -55,6 +112,13 @@ def main():
            'note': 'FETCH_SIZE/WRITE_SIZE are KiB; gfx950 reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM), hence '
                    'fetch_corrected_x2; Infinity-Cache hits are counted too, so this is an upper bound on HBM reads',
            'kernels': dict(list(kernels.items())[:14])}
+    if seq_file:
+        doc['conv_per_shape'] = per_shape(fetch_dir, write_dir, seq_file)
+        for r in doc['conv_per_shape'].get('rows', [])[:60]:
+            print(f"{r['kernel']:18s} x{r['launches_per_step']:3d} {r['avg_us']:7.1f} us {r['tflops']:7.1f} TF/s  alg {r['alg_mb']:7.1f} MB  pmc {r['pmc_mb']:7.1f} MB  "
+                  f"x{r['pmc_over_alg']:.2f}  {r['shape']}")
+        if 'error' in doc['conv_per_shape']:
+            print('per-shape:', doc['conv_per_shape']['error'])
     with open(out, 'w') as f:
         json.dump(doc, f, indent=1)
     for k, v in list(kernels.items())[:8]:
