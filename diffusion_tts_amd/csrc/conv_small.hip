@@ -221,8 +221,11 @@ extern "C" int dts_conv_in3(const float* x, const float* w, const float* bias, v
   const long long nseg = (long long)n * h * (w_ / 16);
   if (dtype != DTS_F32 && w_ % 16 == 0 && (cout == 192 || cout == 128 || cout == 64) && nseg < (1ll << 31) &&
       (bias == nullptr || ((uintptr_t)bias & 15) == 0)) {
-    long long g = (nseg + 31) / 32;                      // 8 segments per wave: the 7*NT weight registers are loaded once per wave
-    if (g < 1) g = 1;
+    // up to 8 segments per wave (the 7*NT weight registers are loaded once per wave), fewer when that would leave CUs idle
+    long long spw = nseg / 2048;
+    if (spw < 1) spw = 1;
+    if (spw > 8) spw = 8;
+    long long g = (nseg + 4 * spw - 1) / (4 * spw);
     if (g > 2048) g = 2048;
 #define DTS_IN3_MFMA(TT, NT_)                                                                                                    \
   hipLaunchKernelGGL((conv_in3_mfma_kernel<TT, NT_>), dim3((int)g), dim3(256), 0, st, x, w, bias, (TT*)out, (int)nseg, h, w_)
