@@ -22,7 +22,7 @@ class ConvArgs(C.Structure):
                 ('n', C.c_int32), ('hin', C.c_int32), ('win', C.c_int32), ('cout', C.c_int32),
                 ('ksize', C.c_int32), ('up', C.c_int32), ('out_scale', C.c_float), ('dtype', C.c_int32),
                 ('workspace', _p), ('workspace_bytes', C.c_int64), ('stats_out', _p), ('stats_written', C.c_int32),
-                ('ev_start', _p), ('ev_stop', _p), ('gn_coef', _p), ('gn_silu', C.c_int32), ('splitk_counters', _p)]
+                ('ev_start', _p), ('ev_stop', _p), ('gn_coef', _p), ('gn_silu', C.c_int32)]
 
 
 # name -> argtypes (every function returns int status except the three noted below)
@@ -63,8 +63,7 @@ SIGNATURES = {
 OTHER = {'dts_version': ([], _i), 'dts_conv_fuses_gn': ([C.POINTER(ConvArgs)], _i), 'dts_set_tuning': ([_i, _i], _i), 'dts_get_tuning': ([_i], _i), 'dts_last_error': ([], C.c_char_p), 'dts_gn_ws_floats': ([_i, _i], _i64)}
 
 _lib = None
-SPLITK_COUNTERS = 4096         # include/dts.h DTS_SPLITK_COUNTERS
-ABI_VERSION = 106              # include/dts.h DTS_ABI_VERSION this binding was written against (ConvArgs = 184 bytes)
+ABI_VERSION = 105              # include/dts.h DTS_ABI_VERSION this binding was written against (ConvArgs = 176 bytes)
 
 
 def load():
@@ -83,7 +82,7 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes, fn.restype = argt, rest
     got = lib.dts_version()
-    if got != ABI_VERSION or C.sizeof(ConvArgs) != 184:
+    if got != ABI_VERSION or C.sizeof(ConvArgs) != 176:
         raise RuntimeError(f'{LIB_PATH} has ABI version {got}, this binding needs {ABI_VERSION}: rebuild with `python -m diffusion_tts_amd.build --force`')
     _lib = lib
     return lib
@@ -95,7 +94,7 @@ def check(status, what=''):
         raise RuntimeError(f'libdts_hip {what} failed ({status}): {msg}')
 
 
-KNOBS = {'att_xcd': 0, 'att_qt': 1, 'conv_tile': 2, 'conv_splits': 3, 'conv_variant': 4, 'gn_fuse': 5, 'att_db': 6, 'conv_fixup': 7}
+KNOBS = {'att_xcd': 0, 'att_qt': 1, 'conv_tile': 2, 'conv_splits': 3, 'conv_variant': 4, 'gn_fuse': 5, 'att_db': 6}
 
 
 def set_tuning(name, value):

@@ -24,7 +24,7 @@
 #include <hip/hip_ext.h>
 #include <type_traits>
 
-static_assert(sizeof(dts_conv_args) == 184, "dts_conv_args layout changed: bump DTS_ABI_VERSION and update the bindings (_lib.py ConvArgs)");
+static_assert(sizeof(dts_conv_args) == 176, "dts_conv_args layout changed: bump DTS_ABI_VERSION and update the bindings (_lib.py ConvArgs)");
 
 namespace {
 
@@ -32,10 +32,7 @@ namespace {
 struct ConvCall {
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // optional dispatch-attached timing events (dts_conv_args)
   bool stats_written = false;
-  unsigned* fix_ctr = nullptr;                          // dts_conv_args.splitk_counters (DTS_SPLITK_COUNTERS zeroed words) or null
 };
-
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_v;
 
 struct ConvP {
   const char* x1; const char* x2;
@@ -60,7 +57,6 @@ struct ConvP {
   int w_shift, hw_shift;   // log2(wout), log2(hout*wout) when both are powers of two, else -1 (pixel coordinates by division)
   const float* gn_coef;    // optional [n][cin][2] (a, b): GroupNorm of the INPUT applied on the staged halo tile (conv_pp_kernel only)
   int gn_silu;
-  unsigned* fix_ctr;       // split-K: per-tile arrival counters (zero between launches) => the last split block of a tile reduces the slabs itself
 };
 
 template <typename T> struct Mma;
@@ -333,11 +329,26 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
 }
 
 // ---- epilogue of one (cout tile, pixel tile[, K split]): lane holds couts co..co+3 of pixel pp for each (mt, nt)
-// ---- everything after the K reduction is complete: lane holds couts co..co+3 of pixel pp for each (mt, nt)
 template <typename T, int MT, int NT, int BM, int BN, int NTHR = 256>
-__device__ __forceinline__ void conv_epilogue_tail(const ConvP& kp, f32x4_t (&acc)[MT][NT], int cm0, const TileMap& tm, int wm, int wn,
-                                                   int lrow, int lq, char* smem, bool bias_in_acc, int stage_off, int early_u0, int early_u1) {
+__device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT][NT], int cm0, const TileMap& tm, int split, int wm, int wn,
+                                              int lrow, int lq, char* smem, bool bias_in_acc, int stage_off, int early_u0, int early_u1) {
   const int p_P = kp.P, p_cout = kp.cout, p_hout = kp.hout, p_wout = kp.wout;
+  // ---- epilogue: lane holds couts co..co+3 of pixel pp for each (mt, nt): one 4-element vector load/store
+  if (kp.splits > 1) {
+    float* part = kp.partial + (size_t)split * p_P * p_cout;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int pp = tm.pix(wn * 16 * NT + nt * 16 + lrow);
+      if (pp >= p_P) continue;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int co = cm0 + wm * 16 * MT + mt * 16 + lq * 4;
+        *reinterpret_cast<float4*>(part + (size_t)pp * p_cout + co) =
+            make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+      }
+    }
+    return;
+  }
   if constexpr (sizeof(T) == 2) {
     if (tm.pn0 + BN <= p_P) {                          // block-uniform
       const bool r_ = kp.residual != nullptr, b_ = kp.bias_nc != nullptr, s_ = NT == 4 && kp.stats != nullptr;
@@ -459,81 +470,6 @@ __device__ __forceinline__ void conv_epilogue_tail(const ConvP& kp, f32x4_t (&ac
       __builtin_nontemporal_store(v_, reinterpret_cast<u32x4_nt*>(outb + (size_t)tm.pix(row) * p_cout * 2 + c * 16));
     }
   }
-}
-
-template <typename T, int MT, int NT, int BM, int BN, int NTHR = 256>
-__device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT][NT], int cm0, const TileMap& tm, int split, int wm, int wn,
-                                              int lrow, int lq, char* smem, bool bias_in_acc, int stage_off, int early_u0, int early_u1) {
-  const int p_P = kp.P, p_cout = kp.cout, p_hout = kp.hout, p_wout = kp.wout;
-  // ---- epilogue: lane holds couts co..co+3 of pixel pp for each (mt, nt): one 4-element vector load/store
-  if (kp.splits > 1 && kp.fix_ctr == nullptr) {
-    float* part = kp.partial + (size_t)split * p_P * p_cout;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int pp = tm.pix(wn * 16 * NT + nt * 16 + lrow);
-      if (pp >= p_P) continue;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int co = cm0 + wm * 16 * MT + mt * 16 + lq * 4;
-        *reinterpret_cast<float4*>(part + (size_t)pp * p_cout + co) =
-            make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
-      }
-    }
-    return;
-  }
-  if (sizeof(T) == 2 && kp.splits > 1) {
-    // In-kernel fix-up (whole 16-bit tiles; the launcher guarantees it): every split block stores its f32 slab tile and the
-    // block that arrives LAST at the tile's counter sums the slabs -- in split order, so the result does not depend on who was
-    // last and equals the two-pass reduce bit for bit -- and runs the ordinary epilogue (bias, residual, rounding, strip
-    // statistics).  No second launch, no slab re-read by another kernel.  Cross-XCD hand-off (the 8 XCD L2s are not coherent for
-    // plain accesses) by the sc1 protocol of MI355X_MICROARCH.md: all slab stores and loads carry sc1 (written through / read
-    // around the non-coherent caches), every storing wave drains vmcnt before the workgroup barrier, ONE lane then adds to
-    // the agent-scope counter, and the block whose add returns splits-1 loads only after that add has returned.
-    const uint32_t slab_bytes = (uint32_t)p_P * (uint32_t)p_cout * 4u;            // < 2^32: the launcher checks the whole slab area
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(kp.partial, 0, (int)(slab_bytes * (uint32_t)kp.splits), 0x00020000);
-    uint32_t off[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-      off[nt] = ((uint32_t)tm.pix(wn * 16 * NT + nt * 16 + lrow) * (uint32_t)p_cout + (uint32_t)(cm0 + wm * 16 * MT + lq * 4)) * 4u;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_v, acc[mt][nt]), rs, off[nt] + mt * 64, (uint32_t)split * slab_bytes, 16);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    volatile int* flag = reinterpret_cast<volatile int*>(smem);                 // the ring is idle: K loop done, barrier passed
-    if (threadIdx.x == 0) {
-      unsigned* ctr = kp.fix_ctr + blockIdx.x;
-      const unsigned prev = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = prev == (unsigned)kp.splits - 1u;
-      if (last) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
-      *flag = last;
-    }
-    __syncthreads();
-    const int last = *flag;
-    __syncthreads();                                   // everyone has read the flag before the epilogue reuses the ring
-    if (!last) return;
-    // (accumulators of their own + a second inlined tail for the sums made hipcc spill on the common path; summing into acc
-    // costs the common path 48 register moves and 12 scratch accesses per block, outside the K loop)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    for (int s_ = 0; s_ < kp.splits; ++s_) {            // fixed order over the splits
-      const uint32_t so = (uint32_t)s_ * slab_bytes;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const u32x4_v v = __builtin_amdgcn_raw_buffer_load_b128(rs, off[nt] + mt * 64, so, 16);
-          acc[mt][nt] += __builtin_bit_cast(f32x4_t, v);
-        }
-    }
-    bias_in_acc = false;
-    stage_off = early_u0 = early_u1 = 0;
-  }
-  conv_epilogue_tail<T, MT, NT, BM, BN, NTHR>(kp, acc, cm0, tm, wm, wn, lrow, lq, smem, bias_in_acc, stage_off, early_u0, early_u1);
 }
 
 // PF: both k-substeps' fragments are read ahead of the first MFMA (40 more VGPRs; the second set lands while the first
@@ -1186,13 +1122,6 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_stats_kernel(const Con
   }
 }
 
-// may this split-K launch reduce its slabs in-kernel (conv_epilogue's fix-up)?  DTS_CONV_FIXUP=0 keeps the two-pass form (A/B aid).
-template <typename T>
-bool splitk_fixup_ok(const ConvCall& call, int splits, int nblk, int P, int BN, int cout) {
-  return sizeof(T) == 2 && splits > 1 && call.fix_ctr != nullptr && nblk <= DTS_SPLITK_COUNTERS && P % BN == 0 &&
-         (long long)splits * P * cout * 4 < (1ll << 32) && dts_knob_get(DTS_KNOB_CONV_FIXUP) != 0;
-}
-
 template <typename T, int MT, int NT, int WM, int WN, bool PF>
 int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, ConvCall& call) {
   constexpr int NW = WM * WN;
@@ -1219,11 +1148,8 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, C
   q.partial = ws;
   // statistics come from the fused epilogue (whole launches, 64-pixel wave strips) or, under split-K, from the reduce pass
   float* const stats_req = p.stats;
-  // split-K fix-up inside the conv kernel (conv_epilogue): whole 16-bit tiles, one zeroed counter per tile, 32-bit slab offsets
-  const bool fix = splitk_fixup_ok<T>(call, splits, nblk, p.P, BN, p.cout);
-  q.fix_ctr = fix ? call.fix_ctr : nullptr;
-  const bool stats_in_reduce = !fix && splits > 1 && stats_req != nullptr && (p.hout * p.wout) % 64 == 0 && p.cout % 4 == 0;
-  if ((splits > 1 && !fix) || NT != 4) q.stats = nullptr;
+  const bool stats_in_reduce = splits > 1 && stats_req != nullptr && (p.hout * p.wout) % 64 == 0 && p.cout % 4 == 0;
+  if (splits > 1 || NT != 4) q.stats = nullptr;
   call.stats_written = q.stats != nullptr || stats_in_reduce;
   const size_t lds = (size_t)2 * (BM + BN) * 128;
   static bool attr_done = false;
@@ -1237,7 +1163,6 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, C
   else
     hipLaunchKernelGGL((conv_igemm_kernel<T, MT, NT, WM, WN, PF>), dim3(nblk, splits), dim3(64 * NW), lds, st, q);
   DTS_CHECK_LAUNCH("dts_conv2d");
-  if (fix) return DTS_OK;
   if (splits > 1 && stats_in_reduce) {
     q.stats = stats_req;
     hipLaunchKernelGGL((conv_splitk_reduce_stats_kernel<T>), dim3(p.P / 64, (p.cout + 63) / 64), dim3(256), 0, st, q);
@@ -1283,10 +1208,8 @@ int launch_conv_pp(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes
     q.splits = splits;
     q.partial = ws;
     float* const stats_req = p.stats;
-    const bool fix = splitk_fixup_ok<T>(call, splits, nblk, p.P, BN, p.cout);
-    q.fix_ctr = fix ? call.fix_ctr : nullptr;
-    const bool stats_in_reduce = !fix && splits > 1 && stats_req != nullptr && (p.hout * p.wout) % 64 == 0 && p.cout % 4 == 0;
-    if (splits > 1 && !fix) q.stats = nullptr;
+    const bool stats_in_reduce = splits > 1 && stats_req != nullptr && (p.hout * p.wout) % 64 == 0 && p.cout % 4 == 0;
+    if (splits > 1) q.stats = nullptr;
     call.stats_written = q.stats != nullptr || stats_in_reduce;
     constexpr size_t lds = (size_t)(6 * 96 + 2 * 328) * 128;      // A: 2 groups x 3 slots x 96 rows; halo: 2 buffers x 328 rows
     static bool attr_done = false;
@@ -1299,7 +1222,6 @@ int launch_conv_pp(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes
     else
       hipLaunchKernelGGL((conv_pp_kernel<T, TAPS, DBG, GN>), dim3(nblk, splits), dim3(512), lds, st, q);
     DTS_CHECK_LAUNCH("dts_conv2d(ping-pong)");
-    if (fix) return DTS_OK;
     if (splits > 1 && stats_in_reduce) {
       q.stats = stats_req;
       hipLaunchKernelGGL((conv_splitk_reduce_stats_kernel<T>), dim3(p.P / 64, (p.cout + 63) / 64), dim3(256), 0, st, q);
@@ -1418,9 +1340,6 @@ extern "C" int dts_conv2d(dts_conv_args* a, dts_stream s) {
   int rc = DTS_OK;
   ConvCall call;
   call.ev_start = (hipEvent_t)a->ev_start; call.ev_stop = (hipEvent_t)a->ev_stop;
-  DTS_CHECK_ARG(a->splitk_counters == nullptr || (uintptr_t)a->splitk_counters % 4 == 0, "dts_conv2d: splitk_counters alignment");
-  call.fix_ctr = (unsigned*)a->splitk_counters;
-  p.fix_ctr = nullptr;
   DTS_DISPATCH_DTYPE(a->dtype, rc = conv_dispatch<T>(p, st, (float*)a->workspace, (long long)a->workspace_bytes, call));
   a->stats_written = call.stats_written ? 1 : 0;
   return rc;

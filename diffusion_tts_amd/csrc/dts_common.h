@@ -47,7 +47,6 @@ enum dts_knob {
   DTS_KNOB_CONV_VARIANT = 4,   // DTS_CONV_VARIANT kernel structure variant (see conv_igemm.hip)
   DTS_KNOB_GN_FUSE = 5,        // DTS_GN_FUSE      reserved for the GroupNorm fusion A/B
   DTS_KNOB_ATT_DB = 6,         // DTS_ATT_DB       1: double-buffered attention K/V tiles (one barrier per key tile); default single-buffered
-  DTS_KNOB_CONV_FIXUP = 7,     // DTS_CONV_FIXUP   0: split-K always as two passes (reduce kernel); default: in-kernel fix-up when counters are given
   DTS_KNOB_COUNT = 16
 };
 int dts_knob_get(int knob);    // defined in elementwise.hip

@@ -93,13 +93,10 @@ CONV_WS_BYTES = 96 << 20        # split-K scratch per device (covers 8 splits of
 
 
 def _conv_workspace(device):
-    """(split-K slab scratch, split-K tile counters) of a device.  The counters start at zero and every launch leaves them zero
-    (include/dts.h dts_conv_args.splitk_counters); one pair per device, so conv launches of a device must be stream-ordered."""
     key = (device.type, device.index)
     ws = _CONV_WS.get(key)
     if ws is None:
-        ws = _CONV_WS[key] = (torch.empty(CONV_WS_BYTES, dtype=torch.uint8, device=device),
-                              torch.zeros(L.SPLITK_COUNTERS, dtype=torch.int32, device=device))
+        ws = _CONV_WS[key] = torch.empty(CONV_WS_BYTES, dtype=torch.uint8, device=device)
     return ws
 
 
@@ -144,9 +141,8 @@ def conv2d(x1, w, bias=None, *, x2=None, bias_nc=None, residual=None, up=False, 
     a.out = _ptr(out, 'out', x1.dtype)
     a.n, a.hin, a.win, a.cout, a.ksize = n, hin, win, cout, kh
     a.up, a.out_scale, a.dtype = int(up), float(out_scale), dt_code(x1.dtype)
-    ws, ctr = _conv_workspace(x1.device)
+    ws = _conv_workspace(x1.device)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
-    a.splitk_counters = ctr.data_ptr()
     st = None
     if gn_stats and (ho * wo) % 64 == 0:
         st = torch.empty(((n * ho * wo) // 64, cout, 2), dtype=torch.float32, device=x1.device)

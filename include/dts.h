@@ -30,9 +30,9 @@ typedef void* dts_stream;
 enum dts_dtype { DTS_F32 = 0, DTS_BF16 = 1, DTS_F16 = 2 };
 enum dts_status { DTS_OK = 0, DTS_ERR_ARG = -1, DTS_ERR_LAUNCH = -2, DTS_ERR_UNSUPPORTED = -3 };
 
-#define DTS_ABI_VERSION 106        /* bumped with every change of a signature or of dts_conv_args (101: ev_start/ev_stop; 102: tuning knobs; 103: dts_cosine_rows; 104: dts_nchw_to_nhwc_pad,
+#define DTS_ABI_VERSION 105        /* bumped with every change of a signature or of dts_conv_args (101: ev_start/ev_stop; 102: tuning knobs; 103: dts_cosine_rows; 104: dts_nchw_to_nhwc_pad,
                                      105: dts_conv_args.gn_coef / gn_silu, dts_conv_fuses_gn;
-                                     head dim 512 in dts_attention; 106: dts_conv_args.splitk_counters) */
+                                     head dim 512 in dts_attention) */
 int dts_version(void);            /* == DTS_ABI_VERSION of the build; a binding must refuse any other value */
 const char* dts_last_error(void);
 /* Tuning knobs (measurement aid; a knob only selects between kernels / block orders with identical results).  knob: index of
@@ -81,14 +81,7 @@ typedef struct dts_conv_args {
                                      normalised tensor is never written (networks.py:168,173-175 feeding conv0 / conv1).  Only launches
                                      for which dts_conv_fuses_gn() returns 1 accept it; padding stays zero (the reference pads AFTER the norm) */
   int32_t gn_silu;                /* 1: act = SiLU, 0: identity */
-  void* splitk_counters;          /* optional: DTS_SPLITK_COUNTERS uint32 words, ZERO before the first call and never touched by the
-                                     caller afterwards (every launch leaves them zero).  With it a split-K launch of whole 16-bit tiles
-                                     reduces its partial sums inside the conv kernel -- the block that arrives last at a tile's counter
-                                     sums the slabs in split order and runs the normal epilogue (statistics included) -- instead of a
-                                     second reduce launch; results are bit-identical to the two-pass form.  One counter array per
-                                     workspace: launches that share it must be stream-ordered, as for the workspace itself */
 } dts_conv_args;
-#define DTS_SPLITK_COUNTERS 4096
 /* 1 if dts_conv2d would apply a->gn_coef inside the conv for this shape / dtype (3x3, cout % 192 == 0, 16-bit, square power-of-two
  * images >= 16, whole 256-pixel tiles, no fused upsample), else 0: the caller then runs dts_gn_apply first. */
 int dts_conv_fuses_gn(const dts_conv_args* a);

@@ -147,43 +147,6 @@ def test_conv_epilogue_emits_group_norm_statistics(ops, dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('n,res,cin,cout,ks,variant', [(4, 8, 768, 768, 3, 0), (2, 16, 576, 576, 3, 0), (2, 32, 384, 384, 3, 1), (3, 16, 384, 1152, 1, 0),
-                                                      (2, 16, 576, 192, 3, 1)])
-def test_split_k_fixup_in_kernel_equals_the_two_pass_reduce(ops, dtype, n, res, cin, cout, ks, variant):
-    """Split-K with the slab reduction done by the last-arriving block of each tile (dts_conv_args.splitk_counters, sc1 hand-off across
-    the XCDs) == split-K with the separate reduce kernel, BIT FOR BIT (both sum the slabs in split order), for the 4-wave and the
-    ping-pong kernel, with residual, bias, scale and strip statistics; the counters are zero again afterwards, run after run."""
-    from diffusion_tts_amd import _lib
-    gen = g(41)
-    x = to_nhwc(ops, q(torch.randn(n, cin, res, res, generator=gen), dtype), dtype)
-    w = ops.pack_conv_weight((torch.randn(cout, cin, ks, ks, generator=gen) / math.sqrt(cin * ks * ks)).to(DEV), dtype)
-    b = torch.randn(cout, generator=gen).to(DEV)
-    r = to_nhwc(ops, q(torch.randn(n, cout, res, res, generator=gen), dtype), dtype)
-    _, ctr = ops._conv_workspace(x.device)
-    outs, stats = [], []
-    try:
-        _lib.set_tuning('conv_variant', variant)
-        for fix in (0, 1, 1, 1):
-            _lib.set_tuning('conv_fixup', fix)
-            y = ops.conv2d(x, w, b, residual=r, out_scale=0.7, gn_stats=True)
-            torch.cuda.synchronize()
-            outs.append(y.clone()); stats.append(y._gn_stats.clone())
-            assert int(ctr.abs().sum()) == 0
-    finally:
-        _lib.set_tuning('conv_variant', -1)
-        _lib.set_tuning('conv_fixup', -1)
-    for y in outs[1:]:
-        assert torch.equal(outs[0], y)
-    yf = outs[0].float().reshape(n * res * res // 64, 64, cout)
-    want = torch.stack([yf.sum(1), (yf * yf).sum(1)], dim=-1)
-    for st in stats:
-        # the two forms cut the pixels into 64-pixel strips differently (linear run vs the ping-pong kernel's 4x16 patch rows): compare per sample
-        per_sample = st.reshape(n, -1, cout, 2).sum(1)
-        assert rel_err(per_sample.cpu(), want.reshape(n, -1, cout, 2).sum(1).cpu()) < 1e-5
-    assert torch.equal(stats[1], stats[2]) and torch.equal(stats[1], stats[3])
-
-
-@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('res,c1,c2,cout', [(16, 128, 0, 192), (32, 64, 128, 384), (64, 192, 0, 192)])
 def test_conv_applies_group_norm_of_its_input(ops, dtype, res, c1, c2, cout):
     """GroupNorm (+ adaptive scale/shift) + SiLU of the input applied inside the 3x3 conv on its staged halo tile == the separate
