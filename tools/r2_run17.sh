@@ -1,0 +1,18 @@
+#!/bin/bash
+set -o pipefail
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2q; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES --output-format csv -d $O/pmc_a -- python3 $R/tools/att_bench.py --n 64 --rounds 3 --variants att_db=0 > $O/pmc_a.log 2>&1; echo "rc a=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_ACTIVE_INST_MISC --output-format csv -d $O/pmc_b -- python3 $R/tools/att_bench.py --n 64 --rounds 3 --variants att_db=0 > $O/pmc_b.log 2>&1; echo "rc b=$?"
+find $O -name "*kernel_trace.csv" -size +20M -delete
+python3 - <<PY
+import csv,glob,collections
+for d in ('pmc_a','pmc_b'):
+    agg=collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob('$O/'+d+'/**/*counter_collection.csv',recursive=True):
+        for r in csv.DictReader(open(f)):
+            if 'attention16' in r['Kernel_Name']:
+                agg[(r['Kernel_Name'][40:90],r['Grid_Size'])][r['Counter_Name']].append(float(r['Counter_Value']))
+    for k,v in agg.items():
+        print(d,k,{c:round(sum(x)/len(x)) for c,x in v.items()})
+PY
