@@ -190,14 +190,13 @@ def conv_roofline(a, run_once, reps, dtype_name, value_per_gpu, gflop_per_eval, 
         # algorithmic bytes of the launch: every input / weight / residual byte read once, every output byte written once
         alg = es * (x1.numel() + (kw['x2'].numel() if kw.get('x2') is not None else 0) + w.numel() + out.numel() +
                     (out.numel() if kw.get('residual') is not None else 0))
-        # which kernel the launcher picks (csrc/conv_igemm.hip conv_dispatch): the ping-pong / halo kernel for eligible 3x3 layers
-        pp = w.shape[1] == 3 and ops.conv_fuses_gn(x1, w, x2=kw.get('x2'), up=bool(kw.get('up'))) and \
-            (kw.get('residual') is None or cin >= 384 or kw.get('gn_coef') is not None)
+        # which kernel the launcher picks (csrc/conv_igemm.hip conv_pick_pp via dts_conv_kernel): the names a kernel trace shows
+        kern = ops.conv_kernel(x1, w, x2=kw.get('x2'), up=bool(kw.get('up')), residual=kw.get('residual'), gn_coef=kw.get('gn_coef'))
+        fam = {6: 'conv_pp_kernel', 4: 'conv_pp_kernel/128'}.get(kern) or ('conv_igemm_kernel/3x3' if w.shape[1] == 3 else 'conv_igemm_kernel/1x1')
         rec.append((2.0 * n_ * ho * wo * co * w.shape[1] * w.shape[2] * w.shape[3], e0, e1,
                     (tuple(x1.shape), tuple(w.shape), 'x2' if kw.get('x2') is not None else '', 'up' if kw.get('up') else '',
                      'res' if kw.get('residual') is not None else '', 'bnc' if kw.get('bias_nc') is not None else '',
-                     'stats' if kw.get('gn_stats') else ''), alg,
-                    'conv_pp_kernel' if pp else ('conv_igemm_kernel/3x3' if w.shape[1] == 3 else 'conv_igemm_kernel/1x1')))
+                     'stats' if kw.get('gn_stats') else ''), alg, fam))
         return out
     ops.conv2d = timed_conv
     was = [c.enabled for c in extra_caches]

@@ -736,11 +736,13 @@ __device__ __forceinline__ uint4 gn_act8(const uint4 v, const float (&ca)[8], co
 // inputs still give identical outputs (ties stay ties).
 // DBG != 0: timing-only diagnostic builds (outputs wrong by construction; tools/conv_bench.py conv_variant=11/21/41/51):
 //   1 = no LDS-DMA after the prologue, 2 = no MFMAs, 4 = every halo piece out of range, 5 = every A piece out of range
-template <typename T, int TAPS, int DBG = 0, bool GN = false>
+template <typename T, int TAPS, int DBG = 0, bool GN = false, int MT = 6>
 __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
-  constexpr int MT = 6, NT = 4, BM = 192, BN = 256, NTHR = 512;
+  // MT = M tiles (of 16 couts) per wave: 6 -> 192-cout blocks (the EDM U-Net widths), 4 -> 128-cout blocks (classifier, SD VAE widths)
+  static_assert(MT == 6 || MT == 4, "cout tile");
+  constexpr int NT = 4, GM = 16 * MT, BM = 2 * GM, BN = 256, NTHR = 512, AJ = MT / 2;      // AJ: A pieces (8 rows x 4 waves) per wave and tile
   constexpr int BKE = 64, ES = 2;
-  constexpr int A_HALF = 96 * 128, A_RING = 3 * A_HALF, H_OFF = 2 * A_RING, H_BUF = 328 * 128;       // see the LDS map above
+  constexpr int A_HALF = GM * 128, A_RING = 3 * A_HALF, H_OFF = 2 * A_RING, H_BUF = 328 * 128;       // see the LDS map above
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const char* const p_x1 = kp.x1; const char* const p_x2 = kp.x2; const char* const p_w = kp.w;
   const int p_c1 = kp.c1, p_c2 = kp.c2, p_cin = kp.cin, W = kp.win, H = kp.hin;
@@ -794,12 +796,12 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
   const int schunk = (chunk ^ (r0 & 7)) * 16;
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
-  // ---- LDS-DMA addressing: (descriptor, 32-bit lane offset, scalar offset).  A share = rows grp*96 + 8*(wi + 4j) + r0 (j < 3) of the
+  // ---- LDS-DMA addressing: (descriptor, 32-bit lane offset, scalar offset).  A share = rows grp*GM + 8*(wi + 4j) + r0 (j < AJ) of the
   // weight tile; weights are stored [cout][tap][cin]: the A tile of (chunk, tap) is at byte (tap*cin + chunk*64) * ES of each row.
   const dts_i32x4 rs_w = make_rsrc(p_w, (uint32_t)((size_t)kp.cout * K * ES));
-  uint32_t avo[3];
+  uint32_t avo[AJ];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) avo[j] = DBG == 5 ? DTS_OOR : (uint32_t)((cm0 + grp * 96 + 8 * (wi + 4 * j) + r0) * K) * ES + schunk;
+  for (int j = 0; j < AJ; ++j) avo[j] = DBG == 5 ? DTS_OOR : (uint32_t)((cm0 + grp * GM + 8 * (wi + 4 * j) + r0) * K) * ES + schunk;
   const uint32_t a_dst = lds_base + grp * A_RING + (8 * wi) * 128;               // + j*32*128 + slot*A_HALF (private ring of group g)
   const uint32_t h_dst = lds_base + H_OFF + (8 * w) * 128;                       // + j*64*128 + buffer*H_BUF  (piece w + 8j)
 
@@ -850,10 +852,10 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
   int a_so = ((ks_begin % p_taps) * p_cin + (ks_begin / p_taps) * BKE) * ES;     // scalar offset of the NEXT A tile this wave issues
   int a_tap = ks_begin % p_taps;
   int a_slot = 0;                                                                 // its ring slot
-#define PP_ISSUE_A()     /* this group's 96 rows of the next A tile */                                         \
+#define PP_ISSUE_A()     /* this group's GM rows of the next A tile */                                          \
   {                                                                                                           \
     const uint32_t d_ = a_dst + a_slot * A_HALF;                                                              \
-    _Pragma("unroll") for (int j = 0; j < 3; ++j) bdma16(avo[j], rs_w, (uint32_t)a_so, d_ + j * (32 * 128));  \
+    _Pragma("unroll") for (int j = 0; j < AJ; ++j) bdma16(avo[j], rs_w, (uint32_t)a_so, d_ + j * (32 * 128));  \
     if (++a_tap == p_taps) { a_tap = 0; a_so += (BKE - (p_taps - 1) * p_cin) * ES; } else a_so += p_cin * ES; \
     if (++a_slot == 3) a_slot = 0;                                                                            \
   }
@@ -871,7 +873,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias_in_acc) b0 = *reinterpret_cast<const float4*>(kp.bias + cm0 + wm * 96 + i * 16 + lq * 4);
+    if (bias_in_acc) b0 = *reinterpret_cast<const float4*>(kp.bias + cm0 + wm * GM + i * 16 + lq * 4);
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{b0.x, b0.y, b0.z, b0.w};
   }
@@ -942,7 +944,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
       if (do_piece) gv = *gp;
       int inflight = 0;                                  // pieces issued in this LOAD: they may still be flying when COMPUTE(t) ends
       if constexpr (DBG != 1) {
-        if (t + 2 < nk) { PP_ISSUE_A(); inflight = 3; }        // A_g(t+2)
+        if (t + 2 < nk) { PP_ISSUE_A(); inflight = AJ; }        // A_g(t+2)
         if (more) {
           if constexpr (p_taps == 9) {
             if (tap < NHP) {
@@ -1000,6 +1002,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
       // everything issued before LOAD(t) has landed -- A_g(t+1), the older halo pieces; only LOAD(t)'s own pieces may fly on
       if (inflight == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else if (inflight == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if (inflight == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       else if (inflight == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_barrier" ::: "memory");
@@ -1177,12 +1180,12 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, C
 }
 
 // ---- ping-pong launcher: one block per (192-cout tile, 256-pixel tile[, K split]); 512 threads, 136 KB of LDS
-template <typename T, int TAPS, int DBG = 0, bool GN = false>
+template <typename T, int TAPS, int DBG = 0, bool GN = false, int MT = 6>
 int launch_conv_pp(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, ConvCall& call) {
   if constexpr (sizeof(T) != 2) {
     return DTS_ERR_UNSUPPORTED;
   } else {
-    constexpr int BM = 192, BN = 256, BKE = 64;
+    constexpr int BM = 32 * MT, BN = 256, BKE = 64;
     ConvP q = p;
     q.n_ct = p.cout / BM;
     q.n_pt = (p.P + BN - 1) / BN;
@@ -1211,16 +1214,16 @@ int launch_conv_pp(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes
     const bool stats_in_reduce = splits > 1 && stats_req != nullptr && (p.hout * p.wout) % 64 == 0 && p.cout % 4 == 0;
     if (splits > 1) q.stats = nullptr;
     call.stats_written = q.stats != nullptr || stats_in_reduce;
-    constexpr size_t lds = (size_t)(6 * 96 + 2 * 328) * 128;      // A: 2 groups x 3 slots x 96 rows; halo: 2 buffers x 328 rows
+    constexpr size_t lds = (size_t)(6 * 16 * MT + 2 * 328) * 128;      // A: 2 groups x 3 slots x 16*MT rows; halo: 2 buffers x 328 rows
     static bool attr_done = false;
     if (!attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<T, TAPS, DBG, GN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<T, TAPS, DBG, GN, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_done = true;
     }
     if (call.ev_start != nullptr && call.ev_stop != nullptr)
-      hipExtLaunchKernelGGL((conv_pp_kernel<T, TAPS, DBG, GN>), dim3(nblk, splits), dim3(512), lds, st, call.ev_start, call.ev_stop, 0, q);
+      hipExtLaunchKernelGGL((conv_pp_kernel<T, TAPS, DBG, GN, MT>), dim3(nblk, splits), dim3(512), lds, st, call.ev_start, call.ev_stop, 0, q);
     else
-      hipLaunchKernelGGL((conv_pp_kernel<T, TAPS, DBG, GN>), dim3(nblk, splits), dim3(512), lds, st, q);
+      hipLaunchKernelGGL((conv_pp_kernel<T, TAPS, DBG, GN, MT>), dim3(nblk, splits), dim3(512), lds, st, q);
     DTS_CHECK_LAUNCH("dts_conv2d(ping-pong)");
     if (splits > 1 && stats_in_reduce) {
       q.stats = stats_req;
@@ -1253,33 +1256,51 @@ bool conv_pp_eligible(int dtype, int ksize, int cout, int c1, int c2, int n, int
          (c1 % 64 == 0) && (c2 % 64 == 0);
 }
 
+// Which kernel a launch takes: 0 = conv_igemm_kernel (4 waves), 6 / 4 = conv_pp_kernel with 192- / 128-cout blocks.  One rule for
+// conv_dispatch and for dts_conv_kernel (what bench.py attributes its per-launch times to).
+// Measured (tools/conv_bench.py --variants, profiles/r02_conv_variants.txt): 3x3 layers +3..11 %, 1x1 layers -10..15 % (their 6-12 K
+// tiles do not amortise the exposed prologue/epilogue of a one-block-per-CU kernel): 3x3 only.  With a residual input the epilogue's
+// residual fetch is exposed in the ping-pong kernel (no early fetch): short-K layers (cin < 384) then lose 2-3 % to the 4-wave kernel.
+int conv_pick_pp(bool f32, const ConvP& p) {
+  const int variant = dts_knob_get(DTS_KNOB_CONV_VARIANT);      // 1 = ping-pong wherever it applies, 0 = never, unset = by shape
+  if (f32 || variant == 0 || dts_knob_get(DTS_KNOB_CONV_TILE) > 0) return 0;
+  // 3x3 only.  The kernel's 1x1 form (TAPS = 1) was 5-20 % slower than the 4-wave kernel on every 1x1 layer, and with more than one
+  // channel chunk it had a landing race: a 1x1 chunk is ONE tile, so the other group's pieces of the next halo are issued one segment
+  // before they are read, but only waited for at the end of that group's COMPUTE, a segment later (3x3 issues them >= 3 segments
+  // ahead).  tools/pp1x1_bisect.py showed it (first launch wrong, later ones often right); the 1x1 dispatch is removed.
+  if (p.taps != 9) return 0;
+  const int mt = p.cout % 192 == 0 ? 6 : (p.cout % 128 == 0 ? 4 : 0);
+  // square power-of-two images of 16..., whole 256-pixel tiles, 32-bit lane offsets, no fused upsample (cout passed as 192: the
+  // divisibility is handled here)
+  if (mt == 0 || !conv_pp_eligible(DTS_BF16, p.taps == 9 ? 3 : 1, 192, p.c1, p.c2, p.n, p.hin, p.win, p.up)) return 0;
+  if ((long long)p.cout * p.taps * p.cin * 2 >= (1ll << 31)) return 0;
+  if (p.gn_coef != nullptr) return mt == 6 ? 6 : 0;              // dts_conv2d has checked dts_conv_fuses_gn
+  if (variant >= 1) return mt;                                   // forced (1) or a timing-only diagnostic build (11/21/41/51)
+  const long long blocks_pp = (long long)(p.cout / (32 * mt)) * ((p.P + 255) / 256);
+  const bool auto_pp = p.taps == 9 && (p.residual == nullptr || p.cin >= 384);
+  return (auto_pp && blocks_pp >= 64) ? mt : 0;
+}
+
 template <typename T>
 int conv_dispatch(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, ConvCall& call) {
   const int g_tile_override = dts_knob_get(DTS_KNOB_CONV_TILE);     // DTS_CONV_TILE=64|128|192 (tuning aid; only honoured when it divides cout)
   int tile = (p.cout % 192 == 0) ? 192 : (p.cout % 128 == 0 ? 128 : 64);    // measured: tools/conv_bench.py
   // f32 (parity mode): the 192-cout tile needs 256 VGPRs and still spills 36 bytes per lane to scratch; take the next tile down
   if (std::is_same<T, float>::value && tile == 192) tile = (p.cout % 128 == 0) ? 128 : 64;
-  // DTS_CONV_VARIANT: 1 = the 8-wave ping-pong kernel wherever it applies (16-bit, cout % 192 == 0), 0 = never, unset = by shape
-  const int variant = dts_knob_get(DTS_KNOB_CONV_VARIANT);
-  // ping-pong / halo kernel: square power-of-two images of 16..., whole 256-pixel tiles, 32-bit lane offsets, no fused upsample
-  const bool pp_ok = conv_pp_eligible(std::is_same<T, float>::value ? DTS_F32 : DTS_BF16, p.taps == 9 ? 3 : 1, p.cout, p.c1, p.c2, p.n,
-                                      p.hin, p.win, p.up);
-  if (!std::is_same<T, float>::value && p.cout % 192 == 0 && g_tile_override <= 0 && pp_ok) {
-    const long long blocks_pp = (long long)(p.cout / 192) * ((p.P + 255) / 256);
-    // measured (tools/conv_bench.py --variants, profiles/r02_conv_variants.txt): 3x3 layers +3..11 %, 1x1 layers -10..15 % (their
-    // 6-12 K tiles do not amortise the exposed prologue/epilogue of a one-block-per-CU kernel): 3x3 only
-    // with a residual input the epilogue's residual fetch is exposed here (no early fetch yet): short-K layers (K = 1728) then lose
-    // 2-3 % to conv_igemm_kernel, longer ones still gain
-    const bool auto_pp = p.taps == 9 && (p.residual == nullptr || p.cin >= 384 || p.gn_coef != nullptr);
-#define DTS_PP(DBG_) (p.taps == 9 ? launch_conv_pp<T, 9, DBG_>(p, st, ws, ws_bytes, call) : launch_conv_pp<T, 1, DBG_>(p, st, ws, ws_bytes, call))
-    if (p.gn_coef != nullptr) return launch_conv_pp<T, 9, 0, true>(p, st, ws, ws_bytes, call);      // dts_conv2d has checked dts_conv_fuses_gn
-    if (variant == 1 || (variant < 0 && auto_pp && blocks_pp >= 64)) return DTS_PP(0);
+  const int pp = conv_pick_pp(std::is_same<T, float>::value, p);
+  if (pp == 6) {
+    const int variant = dts_knob_get(DTS_KNOB_CONV_VARIANT);
+#define DTS_PP(DBG_) launch_conv_pp<T, 9, DBG_>(p, st, ws, ws_bytes, call)
+    if (p.gn_coef != nullptr) return launch_conv_pp<T, 9, 0, true>(p, st, ws, ws_bytes, call);
     if (variant == 11) return DTS_PP(1);     // timing-only diagnostics
     if (variant == 21) return DTS_PP(2);
     if (variant == 41) return DTS_PP(4);
     if (variant == 51) return DTS_PP(5);
+    return DTS_PP(0);
 #undef DTS_PP
   }
+  if (pp == 4)     // 128-cout blocks: the widths that are no multiple of 192 (classifier 128/256/512, SD VAE 128/256/512)
+    return launch_conv_pp<T, 9, 0, false, 4>(p, st, ws, ws_bytes, call);
   if (g_tile_override > 0 && p.cout % g_tile_override == 0) tile = g_tile_override;
   // fragment prefetch pays on the long K loops of the 3x3 layers; f32 (parity mode) keeps the lean order: its 192-cout
   // tile is already at the 256-VGPR limit
@@ -1287,7 +1308,25 @@ int conv_dispatch(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes,
   return conv_dispatch_tile<T, false>(p, tile, st, ws, ws_bytes, call);
 }
 
+// the shape part of ConvP from the C arguments (what the kernel choice depends on)
+void conv_shape_from_args(const dts_conv_args* a, ConvP& p) {
+  p.c1 = a->c1; p.c2 = a->c2; p.cin = a->c1 + a->c2;
+  p.n = a->n; p.hin = a->hin; p.win = a->win;
+  p.hout = a->up ? 2 * a->hin : a->hin; p.wout = a->up ? 2 * a->win : a->win;
+  p.cout = a->cout; p.taps = a->ksize * a->ksize; p.up = a->up;
+  p.P = (int)((long long)p.n * p.hout * p.wout);
+  p.residual = (const char*)a->residual; p.gn_coef = a->gn_coef;
+}
+
 }  // namespace
+
+extern "C" int dts_conv_kernel(const dts_conv_args* a) {
+  if (a == nullptr || (a->ksize != 1 && a->ksize != 3) || a->n <= 0 || a->hin <= 0 || a->win <= 0 || a->cout <= 0) return -1;
+  if ((long long)a->n * a->hin * a->win * (a->up ? 4 : 1) >= (1ll << 30)) return -1;
+  ConvP p;
+  conv_shape_from_args(a, p);
+  return conv_pick_pp(a->dtype == DTS_F32, p);
+}
 
 extern "C" int dts_conv_fuses_gn(const dts_conv_args* a) {
   if (a == nullptr || a->ksize != 3) return 0;

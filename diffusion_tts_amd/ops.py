@@ -109,6 +109,15 @@ def _conv_args(x1, w, x2, up):
     return a
 
 
+def conv_kernel(x1, w, x2=None, up=False, residual=None, gn_coef=None):
+    """Which kernel ops.conv2d launches for these arguments: 0 = 4-wave implicit GEMM, 6 / 4 = ping-pong kernel with 192- / 128-cout
+    blocks (dts_conv_kernel; measurement aid for bench.py)."""
+    a = _conv_args(x1, w, x2, up)
+    a.residual = _ptr(residual)
+    a.gn_coef = _ptr(gn_coef, 'gn_coef', torch.float32)
+    return int(L.load().dts_conv_kernel(C.byref(a)))
+
+
 def conv_fuses_gn(x1, w, *, x2=None, up=False):
     """True if conv2d(x1, w, ..., gn_coef=...) applies the GroupNorm of its input inside the kernel for this shape / dtype
     (the ping-pong / halo kernel: 3x3, cout % 192 == 0, 16-bit, square power-of-two images >= 16, no fused upsample)."""

@@ -30,9 +30,9 @@ typedef void* dts_stream;
 enum dts_dtype { DTS_F32 = 0, DTS_BF16 = 1, DTS_F16 = 2 };
 enum dts_status { DTS_OK = 0, DTS_ERR_ARG = -1, DTS_ERR_LAUNCH = -2, DTS_ERR_UNSUPPORTED = -3 };
 
-#define DTS_ABI_VERSION 105        /* bumped with every change of a signature or of dts_conv_args (101: ev_start/ev_stop; 102: tuning knobs; 103: dts_cosine_rows; 104: dts_nchw_to_nhwc_pad,
+#define DTS_ABI_VERSION 106        /* bumped with every change of a signature or of dts_conv_args (101: ev_start/ev_stop; 102: tuning knobs; 103: dts_cosine_rows; 104: dts_nchw_to_nhwc_pad,
                                      105: dts_conv_args.gn_coef / gn_silu, dts_conv_fuses_gn;
-                                     head dim 512 in dts_attention) */
+                                     head dim 512 in dts_attention; 106: dts_conv_kernel, 128-cout ping-pong blocks) */
 int dts_version(void);            /* == DTS_ABI_VERSION of the build; a binding must refuse any other value */
 const char* dts_last_error(void);
 /* Tuning knobs (measurement aid; a knob only selects between kernels / block orders with identical results).  knob: index of
@@ -85,6 +85,10 @@ typedef struct dts_conv_args {
 /* 1 if dts_conv2d would apply a->gn_coef inside the conv for this shape / dtype (3x3, cout % 192 == 0, 16-bit, square power-of-two
  * images >= 16, whole 256-pixel tiles, no fused upsample), else 0: the caller then runs dts_gn_apply first. */
 int dts_conv_fuses_gn(const dts_conv_args* a);
+/* which kernel dts_conv2d takes for these arguments (shape, dtype, residual / gn_coef presence; tuning knobs included): 0 = the 4-wave
+ * implicit-GEMM kernel, 6 / 4 = the 8-wave ping-pong / halo kernel with 192- / 128-cout blocks, -1 = invalid arguments.  Measurement aid:
+ * bench.py attributes its per-launch times and algorithmic bytes to the kernel name a trace will show. */
+int dts_conv_kernel(const dts_conv_args* a);
 int dts_conv2d(dts_conv_args* a, dts_stream s);      /* writes a->stats_written; no state is kept between calls (thread-safe) */
 
 /* first / last convolutions of the U-Nets (3 image channels; direct, not MFMA) */

@@ -193,6 +193,63 @@ def _check_fused_gn(ops, dtype, n, C_, x1, x2, x1d, x2d, wt, wp, bias, gamma, be
         ops.conv2d(small, w8, None, gn_coef=torch.zeros(1, 64, 2, device=DEV))
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('n,res,c1,c2,cout,ks,extras', [
+    (2, 16, 192, 0, 192, 3, 'res+stats'),          # linear 256-pixel tiles (W = 16), 192-cout blocks
+    (1, 32, 128, 64, 384, 3, 'bnc+stats'),         # 16x16 patches, concat input, two cout tiles
+    (2, 32, 64, 0, 128, 3, 'res+stats'),           # 128-cout blocks (classifier / VAE widths)
+    (1, 64, 128, 0, 256, 3, 'stats'),              # 128-cout blocks, two cout tiles, 64x64 image
+    (2, 16, 256, 256, 512, 3, 'res'),              # 128-cout blocks x 4, concat, linear tiles
+    (1, 16, 768, 0, 128, 3, 'res+stats'),          # one tile per cout block, long K: split-K (whole chunks per split) + reduce pass
+])
+def test_ping_pong_conv_kernel_on_every_kind_of_shape(ops, dtype, n, res, c1, c2, cout, ks, extras):
+    """conv_pp_kernel forced (DTS_CONV_VARIANT=1; the test grids are below the launcher's block-count threshold) against the f32 parity
+    kernel on the same 16-bit-rounded inputs: the only difference allowed is the output rounding (<= 1 ulp of the 16-bit type at
+    the tensor's scale) -- residual, per-sample bias, scale, strip statistics, concat source, 192- and 128-cout blocks, split-K."""
+    from diffusion_tts_amd import _lib
+    gen = g(51)
+    C_ = c1 + c2
+    x1 = q(torch.randn(n, c1, res, res, generator=gen), dtype)
+    x2 = q(torch.randn(n, c2, res, res, generator=gen), dtype) if c2 else None
+    wt = q(torch.randn(cout, C_, ks, ks, generator=gen) / math.sqrt(C_ * ks * ks), dtype)
+    bias = torch.randn(cout, generator=gen).to(DEV)
+    resid = q(torch.randn(n, cout, res, res, generator=gen), dtype) if 'res' in extras else None
+    bnc = q(torch.randn(n, cout, generator=gen), dtype) if 'bnc' in extras else None
+    kw = dict(out_scale=0.8, gn_stats='stats' in extras)
+
+    def run(dt):
+        a = dict(kw)
+        if x2 is not None:
+            a['x2'] = to_nhwc(ops, x2, dt)
+        if resid is not None:
+            a['residual'] = to_nhwc(ops, resid, dt)
+        if bnc is not None:
+            a['bias_nc'] = bnc.to(DEV, dt).contiguous()
+        return ops.conv2d(to_nhwc(ops, x1, dt), ops.pack_conv_weight(wt.to(DEV), dt), bias, **a)
+
+    x1d, wp = to_nhwc(ops, x1, dtype), ops.pack_conv_weight(wt.to(DEV), dtype)
+    _lib.set_tuning('conv_variant', 1)
+    try:
+        assert ops.conv_kernel(x1d, wp, x2=None if x2 is None else to_nhwc(ops, x2, dtype),
+                               residual=None if resid is None else to_nhwc(ops, resid, dtype)) == (6 if cout % 192 == 0 else 4)
+        w1 = ops.pack_conv_weight(q(torch.randn(cout, C_, 1, 1, generator=gen), dtype).to(DEV), dtype)
+        assert ops.conv_kernel(x1d, w1, x2=None if x2 is None else to_nhwc(ops, x2, dtype)) == 0      # 1x1 layers never take it
+        got = run(dtype)
+        again = run(dtype)
+    finally:
+        _lib.set_tuning('conv_variant', -1)
+    ref = run(torch.float32)
+    assert torch.equal(got, again)
+    scale = float(ref.abs().max())
+    ulp = scale * (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11)
+    assert float((got.float() - ref).abs().max()) <= 1.01 * ulp
+    if 'stats' in extras:
+        assert got._gn_stats is not None
+        yf = got.float().reshape(n, res * res, cout)
+        want = torch.stack([yf.sum(1), (yf * yf).sum(1)], dim=-1)          # per sample (the strips of a sample summed)
+        assert rel_err(got._gn_stats.reshape(n, -1, cout, 2).sum(1).cpu(), want.cpu()) < 1e-5
+
+
 def test_conv2d_identical_rows_are_bit_identical(ops):
     """ties must stay ties: the same candidate at different batch positions gives the same bits."""
     gen = g(2)

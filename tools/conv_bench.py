@@ -17,9 +17,17 @@ SHAPES = [  # (name, res, cin, cout, k)
     ('L3 3x3 768->768', 8, 768, 768, 3), ('L3 3x3 1536->768', 8, 1536, 768, 3), ('L3 1x1 768->2304', 8, 768, 2304, 1),
 ]
 
+SHAPES_128 = [  # widths that are no multiple of 192: the ImageNet classifier (n = batch) and the SD VAE decoder (use --n 4)
+    ('CLS 64x64 128->128', 64, 128, 128, 3), ('CLS 32x32 128->256', 32, 128, 256, 3), ('CLS 32x32 256->256', 32, 256, 256, 3),
+    ('CLS 8x8 512->512', 8, 512, 512, 3),
+    ('VAE 64x64 512->512', 64, 512, 512, 3), ('VAE 128x128 512->512', 128, 512, 512, 3), ('VAE 256x256 512->256', 256, 512, 256, 3),
+    ('VAE 256x256 256->256', 256, 256, 256, 3), ('VAE 512x512 256->128', 512, 256, 128, 3), ('VAE 512x512 128->128', 512, 128, 128, 3),
+]
+
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--set', default='adm', choices=['adm', '128'], help="layer shapes: the ADM U-Net's, or the 128-multiple widths")
     ap.add_argument('--n', type=int, default=64)
     ap.add_argument('--dtype', default='bf16')
     ap.add_argument('--iters', type=int, default=10)
@@ -27,6 +35,8 @@ def main():
     ap.add_argument('--no-res', action='store_true', help='no residual input')
     ap.add_argument('--variants', nargs='*', default=None, help='e.g. conv_variant=0 conv_variant=1 (interleaved A/B)')
     a = ap.parse_args()
+    if a.set == '128':
+        SHAPES[:] = SHAPES_128
     if a.variants:
         return ab(a)
     dt = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[a.dtype]

@@ -39,6 +39,8 @@ def conv_dispatches(directory, counter):
                 fam = n.split('<')[0]
                 if fam == 'conv_igemm_kernel':
                     fam += '/3x3' if n.endswith('true>') else '/1x1'
+                elif n.endswith(', 4>'):
+                    fam += '/128'
                 out.append((int(r['Dispatch_Id']), fam, float(r['Counter_Value'])))
     out.sort()
     return [(k, v) for _, k, v in out]
@@ -98,7 +100,8 @@ def main():
     fam = {}
     # families as bench.py names them: the ping-pong / halo kernel, and the 4-wave kernel's 3x3 (fragment-prefetch instantiation,
     # last template argument true) and 1x1 launches
-    pick = {'conv_pp_kernel': lambda k: k.startswith('conv_pp_kernel'),
+    pick = {'conv_pp_kernel': lambda k: k.startswith('conv_pp_kernel') and not k.endswith(', 4>'),
+            'conv_pp_kernel/128': lambda k: k.startswith('conv_pp_kernel') and k.endswith(', 4>'),
             'conv_igemm_kernel/3x3': lambda k: k.startswith('conv_igemm_kernel') and k.endswith('true>'),
             'conv_igemm_kernel/1x1': lambda k: k.startswith('conv_igemm_kernel') and k.endswith('false>'),
             'conv_igemm_kernel': lambda k: k.startswith('conv_igemm_kernel')}
