@@ -96,12 +96,14 @@ __global__ void gn_coef_kernel(const float* __restrict__ partial, int splits, in
 // coefficients from the per-64-pixel-strip statistics the producing convolutions emitted (conv_igemm.hip epilogue).
 // One wave per (group, sample): lane-strided sum over the group's strips x channels, fixed-order f64 wave reduction,
 // then the group's channels get their (a, b).
+// With many strips per sample (SD VAE: 4096 at 512x512) the block is four waves that split the element range and are combined in
+// wave order through LDS (still a fixed order); the U-Net levels (<= 64 strips) keep one wave, whose arithmetic is unchanged.
 template <typename T>
-__global__ __launch_bounds__(64) void gn_coef_strips_kernel(const float* __restrict__ st1, int c1, const float* __restrict__ st2,
+__global__ __launch_bounds__(256) void gn_coef_strips_kernel(const float* __restrict__ st1, int c1, const float* __restrict__ st2,
                                                              int c2, int strips, int groups, int hw, float eps,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const T* __restrict__ ss, int ld_ss, float* __restrict__ coef) {
-  const int C = c1 + c2, cg = C / groups, g = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
+  const int C = c1 + c2, cg = C / groups, g = blockIdx.x, n = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
   double a = 0.0, b = 0.0;
   const int total = strips * cg;
   const float inv_cg = 1.0f / (float)cg;
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(64) void gn_coef_strips_kernel(const float* __restr
     psh[u] = (ok && ss) ? ld1<T>(ss + (size_t)n * ld_ss + C + c) : 0.f;
   }
   // eight independent loads per trip: the kernel is one dependent-latency chain per trip, so the trip count is its run time
-  for (int e0 = lane; e0 < total; e0 += 64 * 8) {
+  for (int e0 = wv * 64 * 8 + lane; e0 < total; e0 += nw * 64 * 8) {
     float2 q[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -135,6 +137,14 @@ __global__ __launch_bounds__(64) void gn_coef_strips_kernel(const float* __restr
   }
   a = wave_sum(a);
   b = wave_sum(b);
+  if (nw > 1) {                                        // block-uniform
+    __shared__ double part[4][2];
+    if (lane == 0) { part[wv][0] = a; part[wv][1] = b; }
+    __syncthreads();
+    if (wv != 0) return;
+    a = part[0][0]; b = part[0][1];
+    for (int k = 1; k < nw; ++k) { a += part[k][0]; b += part[k][1]; }
+  }
   const double cnt = (double)hw * cg;
   const double mean = a / cnt;
   double var = b / cnt - mean * mean;
@@ -430,7 +440,8 @@ extern "C" int dts_gn_coef_strips(const float* st1, int c1, const float* st2, in
   DTS_CHECK_ARG(n <= 65535, "dts_gn_coef_strips: n too large for grid.y");
   hipStream_t st = to_stream(s);
   DTS_DISPATCH_DTYPE(dtype, {
-    hipLaunchKernelGGL((gn_coef_strips_kernel<T>), dim3(groups, n), dim3(64), 0, st, st1, c1, st2, c2, hw / 64, groups, hw, eps,
+    const int threads = (long long)(hw / 64) * (C / groups) > 4096 ? 256 : 64;
+    hipLaunchKernelGGL((gn_coef_strips_kernel<T>), dim3(groups, n), dim3(threads), 0, st, st1, c1, st2, c2, hw / 64, groups, hw, eps,
                        gamma, beta, (const T*)scale_shift, ld_ss, coef);
     DTS_CHECK_LAUNCH("dts_gn_coef_strips");
   });
