@@ -280,7 +280,17 @@ class Job:
         ndev = max(1, torch.cuda.device_count())
         self.dev = torch.device('cuda', (local % ndev) if self.world > 1 else 0)
         self.backend = None
-        if self.world > 1:
+        # DTS_SHARD_ALWAYS_COLLECT=1 with one rank: a one-rank RCCL group whose collectives are all issued (parallel.py) -- the way to
+        # run the RCCL code path of the sharded iteration on a one-GPU box
+        self.dist_on = self.world > 1 or os.environ.get('DTS_SHARD_ALWAYS_COLLECT', '0') == '1'
+        if self.dist_on:
+            if self.world == 1:
+                import socket
+                with socket.socket() as so:
+                    so.bind(('127.0.0.1', 0))
+                    port = so.getsockname()[1]
+                for k_, v_ in (('MASTER_ADDR', '127.0.0.1'), ('MASTER_PORT', str(port)), ('RANK', '0'), ('WORLD_SIZE', '1')):
+                    os.environ.setdefault(k_, v_)
             os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
             torch.cuda.set_device(self.dev)
             # RCCL over xGMI ("nccl" IS RCCL on ROCm).  DTS_DIST_BACKEND=gloo exists only to rehearse the multi-rank control flow on
@@ -294,12 +304,12 @@ class Job:
         torch.cuda.set_device(self.dev)
 
     def barrier(self):
-        if self.world > 1:
+        if self.dist_on:
             self.dist.barrier(device_ids=[self.dev.index]) if self.backend == 'nccl' else self.dist.barrier()
         self.torch.cuda.synchronize(self.dev)
 
     def max_over_ranks(self, dt):
-        if self.world > 1:
+        if self.dist_on:
             t = self.torch.tensor([dt], dtype=self.torch.float64, device=self.dev if self.backend == 'nccl' else 'cpu')
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             dt = float(t)
@@ -319,7 +329,7 @@ class Job:
         return self.max_over_ranks(time.perf_counter() - t0)
 
     def finish(self):
-        if self.world > 1:
+        if self.dist_on:
             self.dist.destroy_process_group()
 
 

@@ -8,6 +8,7 @@ sharding the N candidates of one search iteration is this build's addition (SURV
     search iteration; every rank then takes the same first-max argmax, so the survivor is known everywhere
     from its index alone and is rebuilt locally from the replicated host noise.
 """
+import os
 from typing import Tuple
 
 import torch
@@ -22,6 +23,9 @@ class CandidateShards:
         self.enabled = enabled and dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank(group) if self.enabled else 0
         self.world = dist.get_world_size(group) if self.enabled else 1
+        # DTS_SHARD_ALWAYS_COLLECT=1: a world of ONE still issues every collective (a one-rank RCCL all-gather / broadcast is a real
+        # communicator and a real kernel): the only way to run the RCCL branch of this file on a one-GPU box (tests/test_gpu_sharded.py)
+        self.solo = self.world == 1 and not (self.enabled and os.environ.get('DTS_SHARD_ALWAYS_COLLECT', '0') == '1')
         self.collectives = 0              # data-path collectives (reward all-gathers, survivor broadcasts)
         self.setup_collectives = 0        # one-off replication of host state (hash scale table, numpy RNG state)
         # RCCL ("nccl") moves device tensors directly over xGMI; gloo moves host tensors.  A tensor on the side the process
@@ -43,7 +47,7 @@ class CandidateShards:
 
     def broadcast_host(self, t: torch.Tensor, src_rank: int = 0) -> torch.Tensor:
         """Replicates a HOST tensor from `src_rank` (group rank) in place and returns it."""
-        if self.world == 1:
+        if self.solo:
             return t
         src = src_rank if self.group is None else dist.get_global_rank(self.group, src_rank)
         if self.host_direct:
@@ -78,7 +82,7 @@ class CandidateShards:
     def gather_rewards(self, local: torch.Tensor, n_candidates: int, rows_per_candidate: int) -> torch.Tensor:
         """local: this rank's rewards for candidates [lo,hi) in candidate-major order, shape [(hi-lo)*rows].
         Returns all N*rows rewards (candidate-major), identical on every rank, on `local`'s device."""
-        if self.world == 1:
+        if self.solo:
             return local
         q, rem = divmod(n_candidates, self.world)
         cap = (q + (1 if rem else 0)) * rows_per_candidate
@@ -100,7 +104,7 @@ class CandidateShards:
 
     def broadcast_from_owner(self, tensor: torch.Tensor, candidate: int, n_candidates: int) -> torch.Tensor:
         """Rejection sampling's survivor image travels once from the rank that owns `candidate`."""
-        if self.world == 1:
+        if self.solo:
             return tensor
         owner = next(r for r in range(self.world) if self.span(n_candidates, r)[0] <= candidate < self.span(n_candidates, r)[1])
         src = owner if self.group is None else dist.get_global_rank(self.group, owner)
@@ -122,7 +126,7 @@ class CandidateShards:
         (edm/main.py:593), which the reference never seeds; replicas must make the same picks, and rank 0's stream is
         exactly the single-process one."""
         import numpy as np
-        if self.world == 1:
+        if self.solo:
             return
         name, keys, pos, has_gauss, cached = np.random.get_state()
         t = torch.cat([torch.from_numpy(keys.astype(np.int64)), torch.tensor([pos, has_gauss], dtype=torch.int64)])

@@ -218,7 +218,7 @@ def _eps_greedy(L: _Loop, t_steps, x_next, labels, p, pre):
     N, K, B = p.N, p.K, x_next.shape[0]
     shape = tuple(x_next.shape)
     L.shards.require_candidates(N, 'eps-greedy / zero-order search')
-    if L.shards.world > 1:
+    if not L.shards.solo:
         # hash()-derived step sizes are salted per process (PYTHONHASHSEED): ranks must share ONE table or their candidates and
         # rebuilt pivots diverge.  Rank 0's table == the single-process run's.
         L.scale_fn = L.shards.replicate_scale_table(L.scale_fn, L.num_steps, K, N)

@@ -93,3 +93,34 @@ def test_sharded_search_equals_single_process(manifest, backend):
             assert got[0][ci]['collectives'] == 4 * params['K']          # ONE reward all-gather per search iteration
         if method == 'REJECTION_SAMPLING':
             assert got[0][ci]['collectives'] == 1 + b                    # rewards once + the winner's image per sample
+
+
+def test_rccl_branch_runs_on_one_gpu_with_a_world_of_one(manifest):
+    """The RCCL ("nccl") branch of parallel.py -- process group created with a device id, device tensors handed straight to
+    all_gather_into_tensor / broadcast -- on this box's ONE GPU: a one-rank group with DTS_SHARD_ALWAYS_COLLECT=1 still issues every
+    collective of the sharded search (a one-rank RCCL collective is a real communicator and a real launch).  Results must equal the
+    plain single-process run, and the collective counts those of the 2-rank runs above."""
+    from conftest import ROOT
+    gp = os.path.join(ROOT, 'tests', 'golden', 'edm_golden.npz')
+    single = _run(manifest, gp, False)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    os.environ['DTS_SHARD_ALWAYS_COLLECT'] = '1'
+    try:
+        p = ctx.Process(target=_worker, args=(0, 1, _free_port(), manifest, gp, q, 'nccl'))
+        p.start()
+        rank, got = q.get(timeout=600)
+        p.join(timeout=120)
+    finally:
+        del os.environ['DTS_SHARD_ALWAYS_COLLECT']
+    assert p.exitcode == 0 and rank == 0
+    for ci, (method, params, b) in enumerate(CASES):
+        ref, me = single[ci], got[ci]
+        for a, c in zip(me['rewards'], ref['rewards']):
+            assert np.array_equal(a, c), method
+        assert all(np.array_equal(a, c) for a, c in zip(me['selected'], ref['selected'])), method
+        assert np.array_equal(me['x'], ref['x']), method
+        if method == 'EPS_GREEDY':
+            assert me['collectives'] == 4 * params['K']
+        if method == 'REJECTION_SAMPLING':
+            assert me['collectives'] == 1 + b
