@@ -535,6 +535,18 @@ def run_eps_greedy(a, job):
                     nets[name] = (n_, s_)
             extra['parity'] = parity_leg(job, orc, {k: nets[k] for k in ('f32', 'f16', 'bf16')})
             log('parity leg done')
+            # the same timed region in the other 16-bit type (f16 is the reference's own CUDA dtype, networks.py:658): both throughput
+            # figures and both index-agreement figures then sit in ONE driver-run record
+            other = 'f16' if a.dtype == 'bf16' else ('bf16' if a.dtype == 'f16' else None)
+            if other is not None:
+                ito = EpsGreedyIteration(job, nets[other][0], nets[other][1], n_total)
+                for s in range(3):
+                    ito(s)
+                dto = job.timed(ito, a.steps, a.warmup)
+                extra['other_dtype'] = {'dtype': other, 'value': round(2 * n_total * a.steps / dto, 2), 'ms_per_step': round(dto / a.steps * 1e3, 3),
+                                        'whole_step_frac': round(2 * n_total * a.steps / dto * GFLOP_PER_EVAL['adm64'] * 1e9 / (PEAK_TFLOPS[other] * 1e12), 4)}
+                del ito
+                log(f"{other}: {extra['other_dtype']['value']} evals/s")
     if rank == 0:
         out = {
             'metric': 'candidate U-Net steps/sec, EDM ImageNet-64 eps-greedy N=64', 'value': round(value, 2),

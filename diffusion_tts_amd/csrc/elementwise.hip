@@ -265,6 +265,50 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
     }
   }
 }
+// the same with 16-byte loads (k % 4 == 0, 16-byte aligned rows): a lane takes four consecutive k per trip, a quarter of the load
+// instructions of the scalar form (27 -> ~13 us for the 64 x 768 x 768 embedding layers, which are pure load-issue work)
+__global__ __launch_bounds__(256) void linear4_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ y, int ldy, int m, int k,
+                                                       int n, int act_in, int act_out, int accumulate) {
+  const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (col >= n) return;
+  const float* wr = w + (size_t)col * k;
+  constexpr int RB = 8;
+  const int row0 = blockIdx.y * RB;
+  float acc[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) acc[r] = 0.f;
+#pragma unroll 2
+  for (int j = lane * 4; j < k; j += 256) {
+    const float4 wv = *reinterpret_cast<const float4*>(wr + j);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      if (row0 + r < m) {
+        float4 xv = *reinterpret_cast<const float4*>(x + (size_t)(row0 + r) * ldx + j);
+        if (act_in) { xv.x = silu_f(xv.x); xv.y = silu_f(xv.y); xv.z = silu_f(xv.z); xv.w = silu_f(xv.w); }
+        acc[r] += xv.x * wv.x;
+        acc[r] += xv.y * wv.y;
+        acc[r] += xv.z * wv.z;
+        acc[r] += xv.w * wv.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RB; ++r) acc[r] = wave_sum(acc[r]);
+  if (lane == 0) {
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      if (row0 + r < m) {
+        float v = acc[r] + (bias ? bias[col] : 0.f);
+        float* o = y + (size_t)(row0 + r) * ldy + col;
+        if (accumulate) v += *o;
+        if (act_out) v = silu_f(v);
+        *o = v;
+      }
+    }
+  }
+}
 __global__ void pos_embedding_kernel(const float* __restrict__ v, const float* __restrict__ freqs, float* __restrict__ out, int n,
                                      int half, int swap) {
   const long long total = (long long)n * half;
@@ -538,7 +582,10 @@ extern "C" int dts_linear(const float* x, int ldx, const float* w, const float* 
                           int act_out, int accumulate, dts_stream s) {
   DTS_CHECK_ARG(x && w && y && m > 0 && k > 0 && n > 0 && ldx >= k && ldy >= n, "dts_linear: bad args");
   ST;
-  hipLaunchKernelGGL(linear_kernel, dim3((n + 3) / 4, (m + 7) / 8), dim3(256), 0, st, x, ldx, w, bias, y, ldy, m, k, n, act_in, act_out, accumulate);
+  if (k % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0)
+    hipLaunchKernelGGL(linear4_kernel, dim3((n + 3) / 4, (m + 7) / 8), dim3(256), 0, st, x, ldx, w, bias, y, ldy, m, k, n, act_in, act_out, accumulate);
+  else
+    hipLaunchKernelGGL(linear_kernel, dim3((n + 3) / 4, (m + 7) / 8), dim3(256), 0, st, x, ldx, w, bias, y, ldy, m, k, n, act_in, act_out, accumulate);
   DTS_CHECK_LAUNCH("dts_linear");
   return DTS_OK;
 }

@@ -393,6 +393,9 @@ def test_linear_and_pos_embedding(ops):
     assert rel_err(got, ref) < 1e-5
     acc = ops.linear(x.to(DEV), w.to(DEV), None, out=got.to(DEV).clone(), accumulate=True).cpu()
     assert rel_err(acc, ref + F.linear(x, w)) < 1e-5
+    for kk in (102, 768, 1000):                 # 102: the scalar-load form (k % 4 != 0); 768 / 1000: 16-byte loads with a ragged last trip
+        x2, w2 = torch.randn(9, kk, generator=gen), torch.randn(21, kk, generator=gen) / math.sqrt(kk)
+        assert rel_err(ops.linear(x2.to(DEV), w2.to(DEV), None).cpu(), F.linear(x2, w2)) < 1e-5
     v = torch.tensor([-1.3, 0.02, 1.09])
     half = 32
     freqs = (1 / 10000) ** (torch.arange(half, dtype=torch.float32) / half)
