@@ -382,6 +382,12 @@ class EpsGreedyIteration:
         return best
 
 
+def scorer_dtype(dtype):
+    """The classifier runs in float16 beside a bfloat16 denoiser (scorers.ImageNetScorer: the reward error is the classifier's)."""
+    import torch
+    return torch.float16 if dtype == torch.bfloat16 else dtype
+
+
 def build_adm(job, dtype, with_scorer=True, scorer_name='imagenet', sd=None):
     import warnings
     from diffusion_tts_amd import init as dinit
@@ -396,7 +402,7 @@ def build_adm(job, dtype, with_scorer=True, scorer_name='imagenet', sd=None):
     if with_scorer:
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
-            scorer = ImageNetScorer(device=job.dev, compute_dtype=dtype, seed=1) if scorer_name == 'imagenet' else BrightnessScorer()
+            scorer = ImageNetScorer(device=job.dev, compute_dtype=scorer_dtype(dtype), seed=1) if scorer_name == 'imagenet' else BrightnessScorer()
     return net, scorer, sd
 
 
@@ -555,7 +561,8 @@ def run_eps_greedy(a, job):
             'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic (N(0,1) latents/noises, random-init weights + weight rule)',
             'config': {'workload': 'EDM ImageNet-64 (ADM 295.9M) eps-greedy search iteration, imagenet scorer, sigma step 5/18',
                        'candidates_total': n_total, 'candidates_per_gpu': it.nl, 'rows_per_step_total': 2 * n_total,
-                       'scorer': a.scorer, 'parallelism': f'candidates sharded x{world}, 1 all-gather of rewards per step'},
+                       'scorer': a.scorer, 'scorer_dtype': str(scorer_dtype(dtype)).split('.')[-1] if a.scorer == 'imagenet' else 'f64',
+                       'parallelism': f'candidates sharded x{world}, 1 all-gather of rewards per step'},
             'rccl_ranks': world if (world > 1 and job.backend == 'nccl') else (0 if world > 1 else 1),
             'dist_backend': job.backend, 'weak_value': None if weak is None else round(weak, 2),
             'roofline': roof, 'cpu_baseline': extra.pop('cpu_baseline', None), 'parity': extra.pop('parity', None),

@@ -28,15 +28,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def get_scorer(backend, scorer_name, device):
-    """main.py:60-71 of the reference."""
+def get_scorer(backend, scorer_name, device, compute_dtype=None):
+    """main.py:60-71 of the reference.  compute_dtype: the search's --dtype; the ImageNet classifier runs in float32 for the parity
+    mode and in float16 otherwise (also beside a bfloat16 denoiser: scorers.ImageNetScorer)."""
     from diffusion_tts_amd import scorers as S
     if scorer_name == 'brightness':
         return S.BrightnessScorer(dtype=torch.float32)
     if scorer_name == 'compressibility':                               # sd/scorers.py:79 normalises by 150000 bytes, edm/scorers.py:177 by 3000
         return S.CompressibilityScorer(dtype=torch.float32, max_size=150000 if backend == 'sd' else 3000)
     if scorer_name == 'imagenet' and backend == 'edm':
-        return S.ImageNetScorer(dtype=torch.float32, device=device)
+        return S.ImageNetScorer(dtype=torch.float32, device=device, compute_dtype=torch.float32 if compute_dtype == torch.float32 else torch.float16)
     if scorer_name == 'clip' and backend == 'sd':
         return S.CLIPScorer(dtype=torch.float32, device=device)        # local HF cache only; raises with instructions otherwise
     raise ValueError(f"Unknown or invalid scorer '{scorer_name}' for backend '{backend}'")
@@ -126,7 +127,7 @@ def main(argv=None):
 
     from diffusion_tts_amd.sampler import SamplingMethod, generate_image_grid, load_network
     dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[args.dtype]
-    scorer = get_scorer('edm', args.scorer, device)
+    scorer = get_scorer('edm', args.scorer, device, compute_dtype=dtype)
     net = load_network(args.network, device=device, dtype=dtype)
     if args.seeds is not None:                                                        # bulk mode: seeds sharded over the ranks
         from diffusion_tts_amd.bulk import generate_seeds
