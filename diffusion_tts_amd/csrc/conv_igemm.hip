@@ -158,6 +158,9 @@ __device__ __forceinline__ void bdma16(uint32_t voff, dts_i32x4 rsrc, uint32_t s
   asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
                : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_off) : "memory", "m0");
 }
+#ifndef PP_LOAD_ORDER
+#define PP_LOAD_ORDER 2
+#endif
 constexpr uint32_t DTS_OOR = 0x80000000u;      // lane offset beyond any tensor here (< 2 GiB each): reads as zeros
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
@@ -927,6 +930,13 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
       const int dh3 = (tap * 11) >> 5;                   // tap / 3 for tap < 9
       const int dlt = (p_taps == 9) ? (dh3 - 1) * hwid + (tap - 3 * dh3 - 1) : 0;
       uint4 fa[MT], fb[NT], ga[MT], gb[NT];
+      // LOAD order, measured on the nine 3x3 ADM shapes (profiles/r02_conv_variants.txt item 12; outputs identical in all three):
+      //   0: fragment reads, then the LDS-DMA pieces, then lgkmcnt(0)                                   1104 TF/s (unweighted mean)
+      //   1: fragment reads, lgkmcnt(0), then the pieces (no reads in the LDS queue while they issue)   1086
+      //   2: the pieces first, then the fragment reads (shipped)                                        1109
+      // DBG 6 / 7 build orders 1 / 2 whatever the default (tools/conv_bench.py conv_variant=61 / 71).
+      constexpr int LOAD_ORDER = DBG == 6 ? 1 : (DBG == 7 ? 2 : PP_LOAD_ORDER);
+      if constexpr (LOAD_ORDER != 2) {
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
         const int row = hc[i] + dlt;
@@ -938,6 +948,8 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
       for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq));
 #pragma unroll
       for (int i = 0; i < MT; ++i) ga[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq + 4));
+      }
+      if constexpr (LOAD_ORDER == 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
       uint4 gv = make_uint4(0, 0, 0, 0);                 // fused GroupNorm: this wave's piece tap-2 of the next halo, read back here
       const bool do_piece = fuse_gn && more && tap >= 2 && tap < NHP + 2 && w + 8 * (tap - 2) < npieces;   // wave-uniform
       uint4* const gp = reinterpret_cast<uint4*>(smem + h_wr_off + (size_t)(8 * (w + 8 * (do_piece ? tap - 2 : 0))) * 128 + lane * 16);
@@ -961,6 +973,20 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
             inflight = 0;                                      // a 1x1 chunk is one tile: everything must land before the next LOAD
           }
         }
+      }
+      if constexpr (LOAD_ORDER == 2) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int row = hc[i] + dlt;
+        const int off = row * 128 + ((lq ^ (row & 7)) << 4);
+        fb[i] = *reinterpret_cast<const uint4*>(sh + off);
+        gb[i] = *reinterpret_cast<const uint4*>(sh + (off ^ 64));              // chunk lq + 4: slot index with bit 2 flipped
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq));
+#pragma unroll
+      for (int i = 0; i < MT; ++i) ga[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq + 4));
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every fragment is in registers: slots / buffers may be refilled
       __builtin_amdgcn_sched_barrier(0);
@@ -1296,6 +1322,8 @@ int conv_dispatch(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes,
     if (variant == 21) return DTS_PP(2);
     if (variant == 41) return DTS_PP(4);
     if (variant == 51) return DTS_PP(5);
+    if (variant == 61) return DTS_PP(6);     // LOAD-order A/B builds (correct outputs)
+    if (variant == 71) return DTS_PP(7);
     return DTS_PP(0);
 #undef DTS_PP
   }
