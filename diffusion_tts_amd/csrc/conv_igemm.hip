@@ -855,13 +855,22 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
   int a_so = ((ks_begin % p_taps) * p_cin + (ks_begin / p_taps) * BKE) * ES;     // scalar offset of the NEXT A tile this wave issues
   int a_tap = ks_begin % p_taps;
   int a_slot = 0;                                                                 // its ring slot
-#define PP_ISSUE_A()     /* this group's GM rows of the next A tile */                                          \
+#define PP_ISSUE_A_PIECES(J0_, J1_)     /* pieces [J0_, J1_) of this group's GM rows of the next A tile */       \
   {                                                                                                           \
     const uint32_t d_ = a_dst + a_slot * A_HALF;                                                              \
-    _Pragma("unroll") for (int j = 0; j < AJ; ++j) bdma16(avo[j], rs_w, (uint32_t)a_so, d_ + j * (32 * 128));  \
+    _Pragma("unroll") for (int j = (J0_); j < (J1_); ++j) bdma16(avo[j], rs_w, (uint32_t)a_so, d_ + j * (32 * 128)); \
+  }
+#define PP_ADVANCE_A()                                                                                        \
+  {                                                                                                           \
     if (++a_tap == p_taps) { a_tap = 0; a_so += (BKE - (p_taps - 1) * p_cin) * ES; } else a_so += p_cin * ES; \
     if (++a_slot == 3) a_slot = 0;                                                                            \
   }
+#define PP_ISSUE_A() { PP_ISSUE_A_PIECES(0, AJ); PP_ADVANCE_A(); }
+  // All AJ weight pieces of tile t+2 go out in LOAD(t).  Issuing some from COMPUTE(t) instead (one after each dozen MFMAs, to even the
+  // ~1100-cycle LOAD and the 768-cycle COMPUTE segments out: profiles/r02_conv_sq_counters.txt) was built twice and measured slower both
+  // times (-3.5 % over the 3x3 ADM shapes, r02_conv_variants.txt items 2b and 13): an issue cycle in COMPUTE is a lost matrix cycle.
+  // DBG 8 builds that split form (one piece in LOAD) for the A/B: tools/conv_bench.py conv_variant=81.
+  constexpr int A_IN_LOAD = DBG == 8 ? 1 : AJ;
 
   // ---- B fragments come from the halo tile: centre row of this lane's pixel for each n tile; a tap adds a uniform row delta
   int hc[NT];
@@ -956,7 +965,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
       if (do_piece) gv = *gp;
       int inflight = 0;                                  // pieces issued in this LOAD: they may still be flying when COMPUTE(t) ends
       if constexpr (DBG != 1) {
-        if (t + 2 < nk) { PP_ISSUE_A(); inflight = AJ; }        // A_g(t+2)
+        if (t + 2 < nk) { PP_ISSUE_A_PIECES(0, A_IN_LOAD); inflight = AJ; }        // A_g(t+2): the rest follows in COMPUTE(t)
         if (more) {
           if constexpr (p_taps == 9) {
             if (tap < NHP) {
@@ -995,6 +1004,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
       // ---------------- COMPUTE(t)
       __builtin_amdgcn_s_setprio(1);
       if constexpr (DBG == 2) {
+        if (t + 2 < nk) { PP_ISSUE_A_PIECES(A_IN_LOAD, AJ); PP_ADVANCE_A(); }
 #pragma unroll
         for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(fa[i].x), "v"(ga[i].w));
 #pragma unroll
@@ -1005,10 +1015,19 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
         // row selects its old zeros).  MEASURED (profiles/r02_gn_fusion.txt): hipcc schedules them as a block after the MFMAs, the
         // matrix pipe idles meanwhile, and the conv loses more (+3.4 ms per step) than the separate apply pass cost (2.5 ms): the
         // fused path is correct (bit-identical, tested) but OFF by default (DTS_GN_FUSE=1 turns it on in networks.py).
+        const bool a_more = DBG != 1 && t + 2 < nk;             // wave-uniform: the condition LOAD(t) issued its pieces under
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i) {
 #pragma unroll
           for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
+          if constexpr (A_IN_LOAD < AJ) {
+            if (i == MT / 2 - 1) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (a_more) PP_ISSUE_A_PIECES(A_IN_LOAD, A_IN_LOAD + 1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
         if constexpr (fuse_gn) {
           if (do_piece) {
             const uint4 gr = gn_act8<T>(gv, gca, gcb, kp.gn_silu);
@@ -1018,9 +1037,18 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
           }
         }
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i) {
 #pragma unroll
           for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], ga[i], gb[j]);
+          if constexpr (A_IN_LOAD + 1 < AJ) {
+            if (i == MT / 2 - 1) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (a_more) PP_ISSUE_A_PIECES(A_IN_LOAD + 1, AJ);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+        if (a_more) PP_ADVANCE_A();
       }
       __builtin_amdgcn_s_setprio(0);
       if constexpr (fuse_gn) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the normalised piece is in LDS
@@ -1042,6 +1070,8 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
   if (grp == 0) asm volatile("s_barrier" ::: "memory");          // matches group 1's last COMPUTE barrier
 #undef PP_SET_SRC
 #undef PP_ISSUE_A
+#undef PP_ISSUE_A_PIECES
+#undef PP_ADVANCE_A
 #undef PP_LOAD_COEF
 #undef PP_GN_PIECE
   __syncthreads();
@@ -1324,6 +1354,7 @@ int conv_dispatch(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes,
     if (variant == 51) return DTS_PP(5);
     if (variant == 61) return DTS_PP(6);     // LOAD-order A/B builds (correct outputs)
     if (variant == 71) return DTS_PP(7);
+    if (variant == 81) return DTS_PP(8);     // weight pieces split between LOAD and COMPUTE (measured slower)
     return DTS_PP(0);
 #undef DTS_PP
   }
