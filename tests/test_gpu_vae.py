@@ -110,3 +110,37 @@ def test_vae_decoder_from_a_diffusers_directory(tmp_path, vg):
     (d / 'config.json').write_text(json.dumps({'act_fn': 'relu'}))
     with pytest.raises(ValueError):
         VAEDecoder.from_pretrained(str(d))
+
+
+def test_sd_beam_search_at_config4_size_with_the_hip_vae_and_clip():
+    """BASELINE config 4 at its own size -- SD beam search B=4, N=16, CLIP scorer, [N,4,64,64] fp16 latents, [N,3,512,512] decodes through the
+    HIP VAE decoder (SD-1.5 width) -- over 2 DDIM steps with the stand-in U-Net and a random-init CLIP: row / decode / scorer-call counts of
+    the reference loop (pipeline_stable_diffusion.py:1074-1170: per step B beams x N candidates, 2N U-Net rows per beam), finite scores, the
+    kept beams are the top-B of each step, and a second run reproduces the first bit for bit."""
+    from diffusion_tts_amd.sd_pipeline import SDSearchPipeline
+    from diffusion_tts_amd.scorers import CLIPScorer, ByteTokenizer
+    from diffusion_tts_amd.vae import VAEDecoder
+    from sd_standins import shape_unet, TinyTextEncoder, TinyTokenizer, tiny_clip
+    B, N, steps = 4, 16, 2
+    dec = VAEDecoder(dinit.vae_decoder_state_dict(seed=5), device=DEV, dtype=torch.float16)
+    unet, te = shape_unet().half().to(DEV), TinyTextEncoder().half().to(DEV)
+    pipe = SDSearchPipeline(unet, dec, device=DEV, text_encoder=te, tokenizer=TinyTokenizer())
+    scorer = CLIPScorer(model=tiny_clip(0), tokenizer=ByteTokenizer(1000, 998, 999), device=DEV)
+    runs = []
+    for rep in range(2):
+        torch.manual_seed(7)
+        lat = torch.randn(1, 4, 64, 64).half()
+        d0 = dec.decodes
+        out, score = pipe(prompt='a photo of a cat', latents=lat, num_inference_steps=steps, score_function=scorer, method='beam',
+                          params={'N': N, 'B': B, 'K': 20, 'lambda': 0.15, 'eps': 0.4, 'S': 8}, output_type='pt')
+        runs.append((out, float(score), dec.decodes - d0))
+    out, score, decodes = runs[0]
+    assert out.images.shape == (1, 3, 512, 512) and out.images.dtype == torch.float16
+    assert out.unet_rows == steps * B * (2 + 2 * N)                              # per beam and step: eps of the beam (cond + uncond) + 2N candidate rows
+    assert len(out.scores) == steps * B * N + B                                  # every candidate scored, then the B finalists
+    assert decodes == steps * B * N + B + 1                                      # ... each decoded once, + the returned image
+    sc = np.array(out.scores, dtype=np.float64)
+    assert np.isfinite(sc).all() and np.isfinite(out.images.float().cpu().numpy()).all()
+    last = sc[(steps - 1) * B * N: steps * B * N]
+    assert abs(score - np.sort(last)[::-1][:B].max()) < 5e-3                     # the winner is one of the last step's top-B (fp16 re-score)
+    assert runs[1][1] == score and torch.equal(runs[1][0].images, out.images) and runs[1][0].scores == out.scores
