@@ -748,7 +748,8 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
   constexpr int A_HALF = GM * 128, A_RING = 3 * A_HALF, H_OFF = 2 * A_RING, H_BUF = 328 * 128;       // see the LDS map above
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const char* const p_x1 = kp.x1; const char* const p_x2 = kp.x2; const char* const p_w = kp.w;
-  const int p_c1 = kp.c1, p_c2 = kp.c2, p_cin = kp.cin, W = kp.win, H = kp.hin;
+  // W, H: OUTPUT image size (= input size, or twice it when the nearest-2x upsample of the input is fused into the halo gather)
+  const int p_c1 = kp.c1, p_c2 = kp.c2, p_cin = kp.cin, W = kp.wout, H = kp.hout, Wi = kp.win, Hi = kp.hin, ups = kp.up ? 1 : 0;
   constexpr int p_taps = TAPS;                           // 9 (3x3) or 1 (1x1): the tap loop is unrolled
   const int p_n_ct = kp.n_ct, p_n_pt = kp.n_pt;
 
@@ -817,7 +818,8 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
     if (hr < hr_total) {
       const int hy = hr / hwid, hx = hr - hy * hwid;
       const int y = y0 + hy - bd, x = x0 + hx - bd;
-      if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) hpix[j] = (img0 * H + y) * W + x;
+      // networks.py:82-83: the upsampled pixel (y, x) is input pixel (y >> 1, x >> 1); padding is applied AFTER the upsample
+      if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) hpix[j] = (img0 * Hi + (y >> ups)) * Wi + (x >> ups);
     }
   }
   uint32_t hvo[NHP];                                   // lane offsets of the halo rows in the current source
@@ -848,7 +850,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
   {                                                                                                           \
     const bool s2_ = (ci0_) >= p_c1;                                                                          \
     const int cs_ = s2_ ? p_c2 : p_c1;                                                                        \
-    rs_x = make_rsrc(s2_ ? p_x2 : p_x1, (uint32_t)((size_t)kp.n * hw * cs_ * ES));                            \
+    rs_x = make_rsrc(s2_ ? p_x2 : p_x1, (uint32_t)((size_t)kp.n * Hi * Wi * cs_ * ES));                       \
     _Pragma("unroll") for (int j = 0; j < NHP; ++j)                                                           \
       hvo[j] = (hpix[j] >= 0 && DBG != 4) ? (uint32_t)(hpix[j] * cs_) * ES + schunk : DTS_OOR;                \
   }
@@ -1306,8 +1308,9 @@ int conv_dispatch_tile(const ConvP& p, int tile, hipStream_t st, float* ws, long
 
 // the shapes the ping-pong / halo kernel takes (and with it the fused GroupNorm apply)
 bool conv_pp_eligible(int dtype, int ksize, int cout, int c1, int c2, int n, int hin, int win, int up) {
-  const long long P = (long long)n * hin * win;
-  return dtype != DTS_F32 && cout % 192 == 0 && !up && hin == win && win >= 16 && (win & (win - 1)) == 0 && P % 256 == 0 &&
+  const int ho = up ? 2 * hin : hin, wo = up ? 2 * win : win;      // the tile geometry lives in OUTPUT coordinates
+  const long long P = (long long)n * ho * wo;
+  return dtype != DTS_F32 && cout % 192 == 0 && ho == wo && wo >= 16 && (wo & (wo - 1)) == 0 && P % 256 == 0 && P < (1ll << 30) &&
          (long long)n * hin * win * (c1 > c2 ? c1 : c2) * 2 < (1ll << 31) && (long long)cout * ksize * ksize * (c1 + c2) * 2 < (1ll << 31) &&
          (c1 % 64 == 0) && (c2 % 64 == 0);
 }
@@ -1330,7 +1333,7 @@ int conv_pick_pp(bool f32, const ConvP& p) {
   // divisibility is handled here)
   if (mt == 0 || !conv_pp_eligible(DTS_BF16, p.taps == 9 ? 3 : 1, 192, p.c1, p.c2, p.n, p.hin, p.win, p.up)) return 0;
   if ((long long)p.cout * p.taps * p.cin * 2 >= (1ll << 31)) return 0;
-  if (p.gn_coef != nullptr) return mt == 6 ? 6 : 0;              // dts_conv2d has checked dts_conv_fuses_gn
+  if (p.gn_coef != nullptr) return (mt == 6 && !p.up) ? 6 : 0;   // dts_conv2d has checked dts_conv_fuses_gn
   if (variant >= 1) return mt;                                   // forced (1) or a timing-only diagnostic build (11/21/41/51)
   const long long blocks_pp = (long long)(p.cout / (32 * mt)) * ((p.P + 255) / 256);
   const bool auto_pp = p.taps == 9 && (p.residual == nullptr || p.cin >= 384);
@@ -1391,7 +1394,7 @@ extern "C" int dts_conv_fuses_gn(const dts_conv_args* a) {
   if (a == nullptr || a->ksize != 3) return 0;
   const int variant = dts_knob_get(DTS_KNOB_CONV_VARIANT);
   if (variant == 0 || dts_knob_get(DTS_KNOB_CONV_TILE) > 0) return 0;
-  if (!conv_pp_eligible(a->dtype, a->ksize, a->cout, a->c1, a->c2, a->n, a->hin, a->win, a->up)) return 0;
+  if (a->up || !conv_pp_eligible(a->dtype, a->ksize, a->cout, a->c1, a->c2, a->n, a->hin, a->win, a->up)) return 0;
   const long long blocks_pp = (long long)(a->cout / 192) * (((long long)a->n * a->hin * a->win + 255) / 256);
   return (variant == 1 || blocks_pp >= 64) ? 1 : 0;              // with gn_coef the kernel choice does not depend on the residual
 }

@@ -201,6 +201,8 @@ def _check_fused_gn(ops, dtype, n, C_, x1, x2, x1d, x2d, wt, wp, bias, gamma, be
     (1, 64, 128, 0, 256, 3, 'stats'),              # 128-cout blocks, two cout tiles, 64x64 image
     (2, 16, 256, 256, 512, 3, 'res'),              # 128-cout blocks x 4, concat, linear tiles
     (1, 16, 768, 0, 128, 3, 'res+stats'),          # one tile per cout block, long K: split-K (whole chunks per split) + reduce pass
+    (2, 16, 192, 0, 384, 3, 'up+stats'),           # nearest-2x upsample fused into the halo gather: 16x16 input -> 32x32 patches
+    (3, 8, 256, 0, 256, 3, 'up+stats'),            # 8x8 input -> 16x16 output (linear tiles), 128-cout blocks
 ])
 def test_ping_pong_conv_kernel_on_every_kind_of_shape(ops, dtype, n, res, c1, c2, cout, ks, extras):
     """conv_pp_kernel forced (DTS_CONV_VARIANT=1; the test grids are below the launcher's block-count threshold) against the f32 parity
@@ -215,7 +217,9 @@ def test_ping_pong_conv_kernel_on_every_kind_of_shape(ops, dtype, n, res, c1, c2
     bias = torch.randn(cout, generator=gen).to(DEV)
     resid = q(torch.randn(n, cout, res, res, generator=gen), dtype) if 'res' in extras else None
     bnc = q(torch.randn(n, cout, generator=gen), dtype) if 'bnc' in extras else None
-    kw = dict(out_scale=0.8, gn_stats='stats' in extras)
+    up = 'up' in extras
+    ro = 2 * res if up else res
+    kw = dict(out_scale=0.8, gn_stats='stats' in extras, up=up)
 
     def run(dt):
         a = dict(kw)
@@ -230,7 +234,7 @@ def test_ping_pong_conv_kernel_on_every_kind_of_shape(ops, dtype, n, res, c1, c2
     x1d, wp = to_nhwc(ops, x1, dtype), ops.pack_conv_weight(wt.to(DEV), dtype)
     _lib.set_tuning('conv_variant', 1)
     try:
-        assert ops.conv_kernel(x1d, wp, x2=None if x2 is None else to_nhwc(ops, x2, dtype),
+        assert ops.conv_kernel(x1d, wp, x2=None if x2 is None else to_nhwc(ops, x2, dtype), up=up,
                                residual=None if resid is None else to_nhwc(ops, resid, dtype)) == (6 if cout % 192 == 0 else 4)
         w1 = ops.pack_conv_weight(q(torch.randn(cout, C_, 1, 1, generator=gen), dtype).to(DEV), dtype)
         assert ops.conv_kernel(x1d, w1, x2=None if x2 is None else to_nhwc(ops, x2, dtype)) == 0      # 1x1 layers never take it
@@ -245,7 +249,7 @@ def test_ping_pong_conv_kernel_on_every_kind_of_shape(ops, dtype, n, res, c1, c2
     assert float((got.float() - ref).abs().max()) <= 1.01 * ulp
     if 'stats' in extras:
         assert got._gn_stats is not None
-        yf = got.float().reshape(n, res * res, cout)
+        yf = got.float().reshape(n, ro * ro, cout)
         want = torch.stack([yf.sum(1), (yf * yf).sum(1)], dim=-1)          # per sample (the strips of a sample summed)
         assert rel_err(got._gn_stats.reshape(n, -1, cout, 2).sum(1).cpu(), want.cpu()) < 1e-5
 

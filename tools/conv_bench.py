@@ -33,6 +33,7 @@ def main():
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--stats', action='store_true', help='also emit the fused GroupNorm strip statistics (as the network does)')
     ap.add_argument('--no-res', action='store_true', help='no residual input')
+    ap.add_argument('--up', action='store_true', help='fused nearest-2x upsample of the input (the listed resolution is the INPUT; implies --no-res)')
     ap.add_argument('--variants', nargs='*', default=None, help='e.g. conv_variant=0 conv_variant=1 (interleaved A/B)')
     a = ap.parse_args()
     if a.set == '128':
@@ -76,8 +77,9 @@ def ab(a):
         x = torch.randn(a.n, r, r, cin, device='cuda').to(dt)
         w = (torch.randn(cout, k, k, cin, device='cuda') / (cin * k * k) ** 0.5).to(dt)
         b = torch.randn(cout, device='cuda')
-        res = None if a.no_res else torch.randn(a.n, r, r, cout, device='cuda').to(dt)
-        outs = [torch.empty(a.n, r, r, cout, device='cuda', dtype=dt) for _ in variants]
+        ro = 2 * r if a.up else r
+        res = None if (a.no_res or a.up) else torch.randn(a.n, r, r, cout, device='cuda').to(dt)
+        outs = [torch.empty(a.n, ro, ro, cout, device='cuda', dtype=dt) for _ in variants]
         ts = [[] for _ in variants]
         stats = [None] * len(variants)
         for rnd in range(a.iters + 1):
@@ -87,7 +89,7 @@ def ab(a):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 torch.cuda._sleep(200_000)
                 e0.record()
-                o = ops.conv2d(x, w, b, residual=res, out=outs[vi], gn_stats=a.stats)
+                o = ops.conv2d(x, w, b, residual=res, out=outs[vi], gn_stats=a.stats, up=a.up)
                 e1.record()
                 torch.cuda.synchronize()
                 stats[vi] = o._gn_stats
@@ -95,10 +97,10 @@ def ab(a):
                     ts[vi].append(e0.elapsed_time(e1))
                 for kk in v:
                     _lib.set_tuning(kk, -1)
-        fl = 2.0 * a.n * r * r * cout * cin * k * k
+        fl = 2.0 * a.n * ro * ro * cout * cin * k * k
         same = all(torch.equal(outs[0], o) for o in outs[1:])
         same_st = all((stats[0] is None) == (s_ is None) and (s_ is None or torch.allclose(stats[0], s_, rtol=1e-5, atol=1e-3)) for s_ in stats[1:])
-        row = f'{name:22s} P={a.n * r * r:7d} K={cin * k * k:6d}'
+        row = f'{name:22s} P={a.n * ro * ro:7d} K={cin * k * k:6d}'
         for vi in range(len(variants)):
             ms = sorted(ts[vi])[len(ts[vi]) // 2]
             tot[vi][0] += fl; tot[vi][1] += ms
