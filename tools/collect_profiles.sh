@@ -24,6 +24,10 @@ grep -v amdgpu.ids $O/final_att.txt > profiles/r02_attention_xcd_n64.txt
 { echo "# tools/pp_stress.py on an MI355X: conv_pp_kernel forced (DTS_CONV_VARIANT=1) on every production shape class, 12 launches each with L2/MALL evictions and idle"
   echo "# gaps in between: every launch bit-identical to the first (outputs and strip statistics) and within one output ulp of the f32 parity kernel."
   grep -v amdgpu $O/final_pp_stress.txt; } > profiles/r02_conv_pp_stress.txt
+{ echo "# tools/sd_bench.py on one MI355X: BASELINE config 4 with this build's parts -- SD beam search B=4, N=16, [N,4,64,64] fp16 latents, candidate-batched U-Net calls"
+  echo "# (stand-in U-Net), fused DDIM candidate step, N-row decodes through the HIP VAE decoder (SD-1.5 width, random init); 4 DDIM steps = 260 candidate decodes."
+  echo "# The CLIP line pays the reference's host-side PIL image processor (transformers CLIPImageProcessor) for every candidate; brightness shows the loop + decoder."
+  grep "^SD beam" $O/final_sd.txt; } > profiles/r02_sd_config4.txt
 tail -2 $O/final_pytest.log
 python - <<'PY'
 import json

@@ -13,6 +13,8 @@ DTS_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 4 --no-kernel-timing > $O
 python tools/vae_bench.py --n 16 > $O/final_vae.txt 2>&1 || exit 1
 DTS_SHARD_ALWAYS_COLLECT=1 NCCL_DEBUG=VERSION python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-e2e --no-kernel-timing > $O/final_bench_rccl1.json 2> $O/final_bench_rccl1.err || exit 1
 python tools/pp_stress.py > $O/final_pp_stress.txt 2>&1 || exit 1
+python tools/sd_bench.py --scorer brightness > $O/final_sd.txt 2>&1 || exit 1
+python tools/sd_bench.py >> $O/final_sd.txt 2>&1 || exit 1
 python tools/att_bench.py --n 64 --variants att_xcd=0 att_xcd=1 > $O/final_att.txt 2>&1 || exit 1
 python bench.py --steps 10 --warmup 2 --dtype f16 --no-cpu-baseline --no-e2e > $O/final_bench_f16.json 2> $O/final_bench_f16.err || exit 1
 cd /tmp && export TMPDIR=/tmp
