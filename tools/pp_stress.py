@@ -25,7 +25,7 @@ for dt in (torch.bfloat16, torch.float16):
         b = torch.randn(cout, device='cuda')
         r = torch.randn(n, res, res, cout, device='cuda').to(dt) if use_res else None
         kern = ops.conv_kernel(x1, w, x2=x2, residual=r)
-        _lib.set_tuning('conv_variant', 1)
+        _lib.set_tuning('conv_variant', int(os.environ.get('PP_STRESS_VARIANT', '1')))
         first = None
         nbad = 0
         for rep in range(12):
