@@ -116,15 +116,15 @@ def test_baseline_config1_ddpmpp_naive_full_trajectory():
 
 
 def test_baseline_config2_ddpmpp_rejection_full_trajectories():
-    """BASELINE.json configs[1] (REJECTION, brightness scorer) at full network size with N=4 of the 16 trajectories (the oracle
-    runs on the host): 4 x 35 rows, one scorer call of 4 and the final one; same survivor, same image."""
+    """BASELINE.json configs[1] AT ITS OWN SIZE: DDPM++ CIFAR-32, REJECTION over all N = 16 trajectories, brightness scorer, all 18 sigma
+    steps (the oracle runs the same 16 x 35 rows on the host): one scorer call of 16 and the final one; same survivor, same image."""
     cfg = ddpmpp_cifar10()
     sd, _ = dinit.refill_degenerate(dinit.edm_state_dict(cfg, 0), 0)
     g = torch.Generator().manual_seed(1)
     latents = torch.randn(1, 3, 32, 32, generator=g)
     labels = torch.eye(10)[torch.tensor([7])]
-    o, h, evals = _full_run(cfg, sd, 'rejection', dict(N=4), latents, labels, seed=0)
-    assert evals == 4 * 35 and h['net_rows'] == 4 * 35
+    o, h, evals = _full_run(cfg, sd, 'rejection', dict(N=16), latents, labels, seed=0)
+    assert evals == 16 * 35 and h['net_rows'] == 16 * 35
     assert (torch.cat([r.flatten() for r in o['rewards']]) - torch.cat([r.flatten() for r in h['rewards']])).abs().max().item() < 5e-5
     # rewards are [B, N] here: decide over the candidate axis
     same, _ = check_decisions([r.t() for r in o['rewards']], o['selected'], h['selected'], 'config 2 rejection')
