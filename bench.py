@@ -64,6 +64,8 @@ def parse(argv=None):
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-e2e', action='store_true')
     ap.add_argument('--no-weak', action='store_true', help='skip the weak-scaling leg of a multi-rank run')
+    ap.add_argument('--no-subrecords', action='store_true', help='default workload only: skip the sub-records (8 candidates per GPU, 32x32 rejection, MCTS slice, f32 scorer, whole-search index agreement)')
+    ap.add_argument('--mcts-slice', type=int, default=64, help='S of the MCTS sub-record of the default line')
     ap.add_argument('--conv-sequence', default=None, help='write the per-launch conv shape sequence of one step (JSON) for tools/pmc_traffic.py')
     ap.add_argument('--conv-table', action='store_true', help='log the per-shape conv launch table of the instrumented steps')
     ap.add_argument('--cpu-sample', type=int, default=64, help='candidates in the CPU-baseline / parity iteration')
@@ -406,7 +408,7 @@ def build_adm(job, dtype, with_scorer=True, scorer_name='imagenet', sd=None):
     return net, scorer, sd
 
 
-def parity_leg(job, orc, nets):
+def parity_leg(job, orc, nets, short_agreement=True):
     """GPU f32 / f16 / bf16 against the oracle iteration `orc` on the SAME 64 inputs, then index agreement of the 16-bit modes with
     the f32 mode over 8 more search iterations (K14-built candidates at eight sigma steps with churn)."""
     import torch
@@ -426,6 +428,8 @@ def parity_leg(job, orc, nets):
         sc = L.score(scorer, x0, lab).float().cpu()
         out[name] = {'max_reward_err': float((sc - orc['rewards']).abs().max()), 'argmax': int(sc.argmax()),
                      'index_equal': bool(int(sc.argmax()) == orc['best'])}
+    if not short_agreement:                # the whole-search leg (teacher_forced_agreement) replaces the 8-iteration sample
+        return out
     steps_i = [2, 3, 5, 7, 9, 11, 13, 14]
     agree = {name: 0 for name in nets if name != 'f32'}
     dev_max = {name: 0.0 for name in agree}                   # largest |reward - f32 reward| over all candidates and iterations
@@ -458,6 +462,64 @@ def parity_leg(job, orc, nets):
     return out
 
 
+def teacher_forced_agreement(job, nets, n=64, K=4, num_steps=18, seed=2024, lambda_param=0.15, eps_p=0.4):
+    """Index agreement of the 16-bit modes over ONE WHOLE config-3 search: 18 sigma steps x K = 4 local-search iterations = 72
+    iterations of N = 64 candidates (edm/main.py:730-860).  The search is driven by the f32 parity mode (its argmax picks the pivot, its
+    Heun step advances the state, edm/main.py:842-860) and every dtype evaluates the SAME state, pivot and candidate set in every iteration
+    ("teacher forcing"), so all 72 decisions stay comparable instead of diverging after the first differing pick.
+    Per 16-bit dtype: picks equal to f32's, the same count over the DECIDABLE iterations (f32 top-2 gap > 2 x the dtype's largest reward
+    deviation from f32 anywhere in the search), the f32 reward given up by each differing pick (regret) and the largest reward deviation."""
+    import numpy as np
+    import torch
+    from diffusion_tts_amd import ops
+    from diffusion_tts_amd.sampler import _Loop
+    from diffusion_tts_amd.parallel import CandidateShards
+    dev = job.dev
+    t_steps = sigma_steps()
+    loops = {name: _Loop(net, dev, num_steps, 40, 0.05, 50, 1.003, None, CandidateShards(enabled=False)) for name, (net, _) in nets.items()}
+    g = torch.Generator().manual_seed(seed)
+    x_cur = (torch.randn(1, 3, 64, 64, generator=g, dtype=torch.float64) * t_steps[0]).to(dev)
+    lab1 = torch.eye(1000)[torch.tensor([7])].to(dev)
+    lab = lab1.repeat(n, 1).contiguous()
+    lam = lambda_param * np.sqrt(3 * 64 * 64)
+    others = [k_ for k_ in nets if k_ != 'f32']
+    picks = {k_: [] for k_ in nets}
+    devs = {k_: [] for k_ in others}
+    regret = {k_: [] for k_ in others}
+    gaps = []
+    for i in range(num_steps):
+        pivot = torch.randn(1, 3, 64, 64, generator=g, dtype=torch.float64).to(dev)           # edm/main.py:737
+        for k in range(K):
+            noise = torch.randn(n, 3, 64, 64, generator=g, dtype=torch.float64).to(dev)
+            mode = (torch.rand(n, generator=g) < (1 - eps_p)).to(torch.int32).to(dev)           # :751 perturb the pivot | fresh noise
+            scale = (torch.rand(n, generator=g) * lam).float().to(dev)
+            cand = ops.candidate_noise(pivot, noise, mode, scale)
+            sc = {}
+            for name, (net, scorer) in nets.items():
+                _, x0 = loops[name].step(x_cur, t_steps[i], t_steps[i + 1], i, cand, lab, nb=n)
+                sc[name] = loops[name].score(scorer, x0, lab).double().cpu()
+                picks[name].append(int(sc[name].argmax()))
+            srt = torch.sort(sc['f32'], descending=True).values
+            gaps.append(float(srt[0] - srt[1]))
+            b = picks['f32'][-1]
+            for name in others:
+                devs[name].append(float((sc[name] - sc['f32']).abs().max()))
+                regret[name].append(float(sc['f32'][b] - sc['f32'][picks[name][-1]]))
+            pivot = ops.candidate_noise(pivot, noise[b:b + 1].contiguous(), mode[b:b + 1].contiguous(), scale[b:b + 1].contiguous())
+        x_cur, _ = loops['f32'].step(x_cur, t_steps[i], t_steps[i + 1], i, pivot, lab1)          # edm/main.py:860
+    iters = num_steps * K
+    out = {'iterations': iters, 'candidates': n, 'driver': 'GPU f32 parity mode (teacher forcing: every dtype sees f32\'s state, pivot and candidates)',
+           'f32_top2_gap': {'min': float(f'{min(gaps):.3e}'), 'median': float(f'{sorted(gaps)[len(gaps) // 2]:.3e}'), 'max': float(f'{max(gaps):.3e}')}}
+    for name in others:
+        dmax = max(devs[name])
+        same = [int(a_ == b_) for a_, b_ in zip(picks[name], picks['f32'])]
+        dec = [j for j, g_ in enumerate(gaps) if g_ > 2 * dmax]
+        out[name] = {'agree': f'{sum(same)}/{iters}', 'agree_decidable': f'{sum(same[j] for j in dec)}/{len(dec)}',
+                     'max_reward_dev_vs_f32': float(f'{dmax:.3e}'), 'max_regret': float(f'{max(regret[name]):.3e}'),
+                     'sum_regret': float(f'{sum(regret[name]):.3e}')}
+    return out
+
+
 def e2e_leg(job, net, scorer, dtype):
     """BASELINE config 3 end to end: generate_image_grid, eps-greedy N=64 K=4, 18 sigma steps, host RNG + uploads included."""
     import torch
@@ -480,6 +542,56 @@ def e2e_leg(job, net, scorer, dtype):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+def sub_records(a, job, net, scorer, dtype, sd):
+    """The other numbers DESIGN.md quotes, measured in the SAME driver-run process as the headline (each with its own ms_per_step and
+    roofline): the per-GPU share of an 8-GPU run (8 candidates), BASELINE configs[1] at 32x32 with its own CPU baseline, an MCTS slice
+    (configs[4] at S = --mcts-slice) and the iteration with the reference's fp32 scorer arithmetic (main.py:69)."""
+    import copy
+    import torch
+    from diffusion_tts_amd.scorers import ImageNetScorer
+    out = {}
+    # (1) 8 candidates per GPU: what each rank of `--gpus 8` runs (N = 64 sharded 8 ways), minus the all-gather
+    it8 = EpsGreedyIteration(job, net, scorer, 8)
+    for s in range(3):
+        it8(s)
+    dt8 = job.timed(it8, 40, 3)
+    v8 = 2 * 8 * 40 / dt8
+    a8 = copy.copy(a)
+    a8.candidates, a8.conv_table, a8.conv_sequence = 8, False, None
+    caches = [net._graphs] + ([scorer.model._graphs] if hasattr(scorer, 'model') else [])
+    roof8 = None if a.no_kernel_timing else conv_roofline(a8, lambda s: it8(s), 2, a.dtype, v8, GFLOP_PER_EVAL['adm64'], caches)
+    out['share_8_per_gpu'] = {'value': round(v8, 2), 'unit': 'candidate U-Net steps/sec per GPU', 'ms_per_step': round(dt8 / 40 * 1e3, 3), 'steps': 40,
+                              'candidates_per_gpu': 8, 'projected_8gpu_value': round(8 * v8, 1),
+                              'note': 'the per-GPU work of --gpus 8 at N=64 (strong scaling), without the reward all-gather', 'roofline': roof8}
+    del it8
+    log(f"sub-record share_8_per_gpu: {out['share_8_per_gpu']['ms_per_step']} ms/step")
+    # (2) the iteration with an fp32 classifier (the reference scores in fp32, main.py:69): what exact-precision scoring costs
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        sc32 = ImageNetScorer(device=job.dev, compute_dtype=torch.float32, seed=1)
+    it32 = EpsGreedyIteration(job, net, sc32, 64)
+    for s in range(3):
+        it32(s)
+    dt32 = job.timed(it32, 10, 2)
+    out['f32_scorer'] = {'value': round(2 * 64 * 10 / dt32, 2), 'unit': 'candidate U-Net steps/sec', 'ms_per_step': round(dt32 / 10 * 1e3, 3), 'steps': 10,
+                         'config': f'{a.dtype} denoiser + float32 classifier (parity-mode scorer kernels), N=64',
+                         'whole_step_frac': round(2 * 64 * 10 / dt32 * GFLOP_PER_EVAL['adm64'] * 1e9 / (PEAK_TFLOPS[a.dtype] * 1e12), 4)}
+    del it32, sc32
+    log(f"sub-record f32_scorer: {out['f32_scorer']['ms_per_step']} ms/step")
+    # (3) MCTS slice (BASELINE configs[4] shape at a smaller S)
+    rec = mcts_record(a, job, a.mcts_slice, 1, 0, built=(net, scorer))
+    out['mcts_s'] = {k_: rec[k_] for k_ in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'config', 'roofline')}
+    log(f"sub-record mcts_s (S={a.mcts_slice}): {rec['value']} evals/s")
+    # (4) BASELINE configs[1]: DDPM++ CIFAR-32 rejection N=16 with its CPU baseline
+    a32 = copy.copy(a)
+    a32.conv_table, a32.conv_sequence, a32.workload, a32.candidates = False, None, 'ddpmpp32_rejection', 16
+    rec = rejection32_record(a32, job, steps=40, warmup=3)
+    out['ddpmpp32_rejection'] = {k_: rec[k_] for k_ in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'config', 'roofline', 'cpu_baseline')}
+    log(f"sub-record ddpmpp32_rejection: {rec['value']} evals/s, cpu {rec['cpu_baseline']}")
+    return out
+
+
 def run_eps_greedy(a, job):
     import torch
     dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[a.dtype]
@@ -539,8 +651,12 @@ def run_eps_greedy(a, job):
                 if name not in nets:
                     n_, s_, _ = build_adm(job, dt_, sd=sd)
                     nets[name] = (n_, s_)
-            extra['parity'] = parity_leg(job, orc, {k: nets[k] for k in ('f32', 'f16', 'bf16')})
+            want_sub = not a.no_subrecords and a.candidates == 64
+            extra['parity'] = parity_leg(job, orc, {k: nets[k] for k in ('f32', 'f16', 'bf16')}, short_agreement=not want_sub)
             log('parity leg done')
+            if want_sub:       # index agreement as a RATE: one whole config-3 search, teacher-forced on the f32 pivots
+                extra['parity']['index_agreement'] = teacher_forced_agreement(job, {k: nets[k] for k in ('f32', 'f16', 'bf16')}, n=64)
+                log(f"whole-search index agreement: {extra['parity']['index_agreement']}")
             # the same timed region in the other 16-bit type (f16 is the reference's own CUDA dtype, networks.py:658): both throughput
             # figures and both index-agreement figures then sit in ONE driver-run record
             other = 'f16' if a.dtype == 'bf16' else ('bf16' if a.dtype == 'f16' else None)
@@ -553,6 +669,9 @@ def run_eps_greedy(a, job):
                                         'whole_step_frac': round(2 * n_total * a.steps / dto * GFLOP_PER_EVAL['adm64'] * 1e9 / (PEAK_TFLOPS[other] * 1e12), 4)}
                 del ito
                 log(f"{other}: {extra['other_dtype']['value']} evals/s")
+            del nets
+        if not a.no_subrecords and a.candidates == 64 and a.scorer == 'imagenet':
+            extra['sub_records'] = sub_records(a, job, net, scorer, dtype, sd)
     if rank == 0:
         out = {
             'metric': 'candidate U-Net steps/sec, EDM ImageNet-64 eps-greedy N=64', 'value': round(value, 2),
@@ -571,7 +690,38 @@ def run_eps_greedy(a, job):
         print(json.dumps(out), flush=True)
 
 
-def run_rejection32(a, job):
+def oracle_rejection32_step(n_total, seed=0):
+    """CPU baseline of the 32x32 workload: the oracle's DDPM++ CIFAR-32 Heun step (sigma step 5, S_churn 40) over the same N trajectories
+    + the brightness score of the predicted images, fp32 torch-CPU on this box's host cores."""
+    import torch
+    from diffusion_tts_amd import init as dinit
+    from diffusion_tts_amd.config import ddpmpp_cifar10
+    from oracle.edm_nets import NetCfg, EDMPrecondOracle
+    from oracle import sampler as osamp, scorers as oscore
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
+    torch.set_num_threads(cores)
+    cfg = ddpmpp_cifar10()
+    sd, _ = dinit.refill_degenerate(dinit.edm_state_dict(cfg, seed), seed)
+    net = EDMPrecondOracle(NetCfg('ddpmpp', 32, 3, 10, 128, [2, 2, 2], 4, 4, [16], 9), sd)
+    t_steps = osamp.sigma_schedule(net, 18)
+    ctx = osamp._Ctx(net, 18, 40, 0.05, 50, 1.003)
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(n_total, 3, 32, 32, generator=g, dtype=torch.float64) * t_steps[5]
+    eps = torch.randn(n_total, 3, 32, 32, generator=g, dtype=torch.float64)
+    lab = torch.eye(10)[torch.tensor([3])].repeat(n_total, 1)
+    scorer = oscore.BrightnessOracle()
+    reps, t0 = 0, time.perf_counter()
+    while reps < 2 or time.perf_counter() - t0 < 4.0:          # a bounded sample: a few seconds of CPU work
+        xn, _ = ctx.heun_step(x, t_steps[5], t_steps[6], 5, eps, lab)
+        sc = scorer(osamp.to_uint8(xn), lab, torch.zeros(n_total))
+        reps += 1
+    dt = time.perf_counter() - t0
+    return {'value': round(2 * n_total * reps / dt, 2), 'unit': 'candidate U-Net steps/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'seconds': round(dt, 2), 'sample': f'{reps} Heun steps of the same workload ({n_total} trajectories = {2 * n_total} DDPM++-32 denoiser rows each, '
+                                               f'+ brightness score), fp32 torch-CPU oracle'}, float(sc.max())
+
+
+def rejection32_record(a, job, steps=None, warmup=None, cpu=True):
     """BASELINE configs[1]: DDPM++ CIFAR-32, rejection sampling over N=16 trajectories, brightness scorer.  One step = one Heun step
     of the N trajectories (2*N candidate U-Net evaluations) + the score of the predicted images; sigma step 5, S_churn = 40."""
     import torch
@@ -583,12 +733,15 @@ def run_rejection32(a, job):
     from diffusion_tts_amd.scorers import BrightnessScorer
     dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[a.dtype]
     world, rank, dev = job.world, job.rank, job.dev
+    steps = a.steps if steps is None else steps
+    warmup = a.warmup if warmup is None else warmup
     cfg = ddpmpp_cifar10()
     sd, _ = dinit.refill_degenerate(dinit.edm_state_dict(cfg, 0), 0)
     net = EDMPrecond(cfg, sd, device=dev, dtype=dtype)
     scorer = BrightnessScorer()
     shards = CandidateShards()
-    n_total = a.candidates * world if a.scaling == 'weak' else a.candidates
+    cand = 16 if a.workload != 'ddpmpp32_rejection' else a.candidates
+    n_total = cand * world if a.scaling == 'weak' else cand
     shards.require_candidates(n_total, 'bench')
     lo, hi = shards.span(n_total)
     nl = hi - lo
@@ -607,72 +760,85 @@ def run_rejection32(a, job):
     for s in range(3):
         one_step(s)
     torch.cuda.synchronize(dev)
-    dt = job.timed(one_step, a.steps, a.warmup)
-    value = 2 * n_total * a.steps / dt
+    dt = job.timed(one_step, steps, warmup)
+    value = 2 * n_total * steps / dt
     roof = None
     if not a.no_kernel_timing:
         if rank == 0:
-            roof = conv_roofline(a, lambda s: one_step(s), min(2, a.steps), a.dtype, value / world, GFLOP_PER_EVAL['ddpmpp32'], [net._graphs])
+            roof = conv_roofline(a, lambda s: one_step(s), min(2, steps), a.dtype, value / world, GFLOP_PER_EVAL['ddpmpp32'], [net._graphs])
         else:
-            for s in range(min(2, a.steps)):
+            for s in range(min(2, steps)):
                 one_step(s)
     job.barrier()
-    if rank == 0:
-        print(json.dumps({
-            'metric': 'candidate U-Net steps/sec, EDM CIFAR-10 32x32 rejection N=16', 'value': round(value, 2),
-            'unit': 'candidate U-Net steps/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-            'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': a.scaling if world > 1 else 'strong',
-            'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic (N(0,1) latents/noises, random-init weights + weight rule)',
-            'config': {'workload': 'EDM CIFAR-10 (DDPM++ 55.7M) rejection-sampling Heun step over the N trajectories, brightness scorer, sigma step 5/18',
-                       'candidates_total': n_total, 'candidates_per_gpu': nl, 'rows_per_step_total': 2 * n_total,
-                       'gflop_per_eval': GFLOP_PER_EVAL['ddpmpp32'], 'parallelism': f'trajectories sharded x{world}'},
-            'roofline': roof, 'cpu_baseline': None}), flush=True)
+    cpu_rec = None
+    if cpu and rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu_rec, _ = oracle_rejection32_step(n_total)
+    return {
+        'metric': 'candidate U-Net steps/sec, EDM CIFAR-10 32x32 rejection N=16', 'value': round(value, 2),
+        'unit': 'candidate U-Net steps/sec', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
+        'ms_per_step': round(dt / steps * 1e3, 3), 'higher_is_better': True, 'scaling': a.scaling if world > 1 else 'strong',
+        'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic (N(0,1) latents/noises, random-init weights + weight rule)',
+        'config': {'workload': 'EDM CIFAR-10 (DDPM++ 55.7M) rejection-sampling Heun step over the N trajectories, brightness scorer, sigma step 5/18',
+                   'candidates_total': n_total, 'candidates_per_gpu': nl, 'rows_per_step_total': 2 * n_total,
+                   'gflop_per_eval': GFLOP_PER_EVAL['ddpmpp32'], 'parallelism': f'trajectories sharded x{world}'},
+        'roofline': roof, 'cpu_baseline': cpu_rec}
 
 
-def run_mcts(a, job):
+def run_rejection32(a, job):
+    rec = rejection32_record(a, job)
+    if job.rank == 0:
+        print(json.dumps(rec), flush=True)
+
+
+def mcts_record(a, job, S, steps, warmup, built=None):
     """BASELINE configs[4]: ADM-64 MCTS, S rollouts per timestep, imagenet scorer.  One step = one whole image search through
     generate_image_grid (18 sigma steps; node expansions batched, ragged rollouts batched and sharded over the ranks)."""
     import numpy as np
     import torch
     from diffusion_tts_amd.sampler import SamplingMethod, generate_image_grid
     dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[a.dtype]
-    net, scorer, _ = build_adm(job, dtype, scorer_name=a.scorer)
+    net, scorer = built if built is not None else build_adm(job, dtype, scorer_name=a.scorer)[:2]
     lat = torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(3))
     lab = torch.eye(1000)[torch.tensor([5])]
 
-    def search(S, seed):
+    def search(S_, seed):
         np.random.seed(seed)
         return generate_image_grid(net, None, lat, lab, seed=seed, gridw=1, gridh=1, device=job.dev, num_steps=18, S_churn=40,
                                    S_min=0.05, S_max=50, S_noise=1.003, sampling_method=SamplingMethod.MCTS,
-                                   sampling_params=dict(scorer=scorer, N=a.mcts_children, S=S), compute_dtype=dtype, verbose=False)
-    search(min(a.S, 16), 0)                     # setup: kernel attributes, graph captures of the common batch sizes
+                                   sampling_params=dict(scorer=scorer, N=a.mcts_children, S=S_), compute_dtype=dtype, verbose=False)
+    search(min(S, 16), 0)                       # setup: kernel attributes, graph captures of the common batch sizes
     rows = [0]
 
     def one_step(s):
-        rows[0] += search(a.S, 1 + s)['net_rows']
-    for s in range(a.warmup):
+        rows[0] += search(S, 1 + s)['net_rows']
+    for s in range(warmup):
         one_step(s)
     rows[0] = 0
-    dt = job.timed(one_step, a.steps, 0)
+    dt = job.timed(one_step, steps, 0)
     rows_total = rows[0]                        # rows of THIS rank; rollouts are sharded, expansions replicated
     if job.world > 1:
         t = torch.tensor([rows_total], dtype=torch.float64, device=job.dev if job.backend == 'nccl' else 'cpu')
         job.dist.all_reduce(t)
         rows_total = int(t)
+    value = rows_total / dt
+    return {
+        'metric': f'candidate U-Net steps/sec, EDM ImageNet-64 MCTS S={S}', 'value': round(value, 2),
+        'unit': 'candidate U-Net steps/sec', 'n_gpus': job.world, 'steps': steps, 'warmup': warmup,
+        'ms_per_step': round(dt / steps * 1e3, 1), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+        'dtype': a.dtype, 'data': 'synthetic (N(0,1) latents/noises, random-init weights + weight rule)',
+        'config': {'workload': f'EDM ImageNet-64 (ADM 295.9M) MCTS search of one image: 18 sigma steps, {a.mcts_children} children per node, '
+                               f'S={S} rollouts per timestep, imagenet scorer', 'denoiser_rows_per_search': rows_total // max(1, steps),
+                   'parallelism': f'rollouts of each group of 16 sharded x{job.world}'},
+        'roofline': {'bound': 'mfma', 'achieved': round(value / job.world * GFLOP_PER_EVAL['adm64'] / 1e3, 1), 'peak': PEAK_TFLOPS[a.dtype],
+                     'unit': 'TFLOP/s', 'frac': round(value / job.world * GFLOP_PER_EVAL['adm64'] * 1e9 / (PEAK_TFLOPS[a.dtype] * 1e12), 4),
+                     'traffic': None, 'kernel': 'whole search (denoiser FLOPs only)'},
+        'cpu_baseline': None}
+
+
+def run_mcts(a, job):
+    rec = mcts_record(a, job, a.S, a.steps, a.warmup)
     if job.rank == 0:
-        value = rows_total / dt
-        print(json.dumps({
-            'metric': f'candidate U-Net steps/sec, EDM ImageNet-64 MCTS S={a.S}', 'value': round(value, 2),
-            'unit': 'candidate U-Net steps/sec', 'n_gpus': job.world, 'steps': a.steps, 'warmup': a.warmup,
-            'ms_per_step': round(dt / a.steps * 1e3, 1), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
-            'dtype': a.dtype, 'data': 'synthetic (N(0,1) latents/noises, random-init weights + weight rule)',
-            'config': {'workload': f'EDM ImageNet-64 (ADM 295.9M) MCTS search of one image: 18 sigma steps, {a.mcts_children} children per node, '
-                                   f'S={a.S} rollouts per timestep, imagenet scorer', 'denoiser_rows_per_search': rows_total // max(1, a.steps),
-                       'parallelism': f'rollouts of each group of 16 sharded x{job.world}'},
-            'roofline': {'bound': 'mfma', 'achieved': round(value / job.world * GFLOP_PER_EVAL['adm64'] / 1e3, 1), 'peak': PEAK_TFLOPS[a.dtype],
-                         'unit': 'TFLOP/s', 'frac': round(value / job.world * GFLOP_PER_EVAL['adm64'] * 1e9 / (PEAK_TFLOPS[a.dtype] * 1e12), 4),
-                         'traffic': None, 'kernel': 'whole search (denoiser FLOPs only)'},
-            'cpu_baseline': None}), flush=True)
+        print(json.dumps(rec), flush=True)
 
 
 def main():

@@ -59,6 +59,8 @@ def check_m0(obj):
     import glob
     import tempfile
     if not os.path.exists(OBJDUMP):
+        # the M0-clobber shortcut of glds16()/bdma16() is only sound while this check passes: say loudly that it did not run
+        print(f'WARNING: {OBJDUMP} not found: the M0 safety check of conv_igemm.o was SKIPPED (set LLVM_OBJDUMP)', file=sys.stderr)
         return -1
     with tempfile.TemporaryDirectory() as tmp:
         local = os.path.join(tmp, 'conv_igemm.o')

@@ -425,11 +425,14 @@ __global__ __launch_bounds__(256) void attention32_kernel(const AttP p) {
 
 template <typename K>
 int launch_att(K kernel, const AttP& p0, size_t lds, hipStream_t st, int qblock = 64, int slices = 1) {
-  {   // hipFuncSetAttribute once per kernel (every instantiation has the same pointer TYPE, so the key is the pointer itself)
+  {   // hipFuncSetAttribute once per (device, kernel): the attribute is per device, and every instantiation has the same pointer
+      // TYPE, so the key is (device, pointer value)
     static std::mutex mu;
-    static std::unordered_map<const void*, size_t> done;
+    static std::unordered_map<uintptr_t, size_t> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     std::lock_guard<std::mutex> lk(mu);
-    size_t& have = done[reinterpret_cast<const void*>(kernel)];
+    size_t& have = done[reinterpret_cast<uintptr_t>(reinterpret_cast<const void*>(kernel)) ^ ((uintptr_t)(dev + 1) << 56)];
     if (lds > have) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       have = lds;

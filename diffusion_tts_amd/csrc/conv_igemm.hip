@@ -131,6 +131,49 @@ template <> struct Vec4<f16_t> {
   }
 };
 
+#ifdef DTS_STAMPS
+// diagnostic build only (tools/conv_stamps.py builds a second library with -DDTS_STAMPS; the product library carries none of this):
+// per block, wave 0 records s_memtime at entry / after the prologue / after the K loop / at exit, and s_memrealtime at entry / exit
+__device__ unsigned long long g_stamps[8192 * 8];
+#define DTS_STAMP(slot_)                                                                                       \
+  if (threadIdx.x == 0 && (blockIdx.x + blockIdx.y * gridDim.x) < 8192) {                                       \
+    unsigned long long t_;                                                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                 \
+    g_stamps[(blockIdx.x + blockIdx.y * gridDim.x) * 8 + (slot_)] = t_;                                         \
+  }
+#define DTS_STAMP_RT(slot_)                                                                                    \
+  if (threadIdx.x == 0 && (blockIdx.x + blockIdx.y * gridDim.x) < 8192) {                                       \
+    unsigned long long t_;                                                                                      \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                             \
+    g_stamps[(blockIdx.x + blockIdx.y * gridDim.x) * 8 + (slot_)] = t_;                                         \
+  }
+// finer: per-wave cycle sums of the sections of conv_pp_kernel's tap loop (wave 0 = group 0, wave 4 = group 1), kept in SGPRs
+#define DTS_SEG_DECL unsigned long long seg_t_ = 0, seg_acc_[6] = {0, 0, 0, 0, 0, 0};
+#define DTS_SEG_START { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(seg_t_)::"memory"); }
+#define DTS_SEG_MARK(i_)                                                                                       \
+  {                                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    unsigned long long n_;                                                                                     \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(n_)::"memory");                                \
+    seg_acc_[i_] += n_ - seg_t_;                                                                               \
+    seg_t_ = n_;                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+  }
+#define DTS_SEG_STORE                                                                                          \
+  if ((threadIdx.x & 255) == 0 && (blockIdx.x + blockIdx.y * gridDim.x) < 4096) {                              \
+    unsigned long long* d_ = g_seg + ((blockIdx.x + blockIdx.y * gridDim.x) * 2 + (threadIdx.x >> 8)) * 8;     \
+    for (int i_ = 0; i_ < 6; ++i_) d_[i_] = seg_acc_[i_];                                                      \
+  }
+__device__ unsigned long long g_seg[4096 * 2 * 8];
+#else
+#define DTS_STAMP(slot_)
+#define DTS_STAMP_RT(slot_)
+#define DTS_SEG_DECL
+#define DTS_SEG_START
+#define DTS_SEG_MARK(i_)
+#define DTS_SEG_STORE
+#endif
+
 __device__ uint4 g_zero16[512];    // 8 KiB of zeros: source of padded (out-of-image) rows; a row pointer into it is advanced
                                    // along K like a real one (cin * element size <= 6 KiB), so no per-step select is needed
 
@@ -317,7 +360,9 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
       }
     }
   }
+  DTS_STAMP(6);
   __syncthreads();
+  DTS_STAMP(7);
   // copy-out: 16 bytes per lane, whole rows; (row, chunk slot) advance incrementally (NTHR threads = DR rows + DC chunks)
   int row = tid / CPR, c = tid - row * CPR;
   char* outb = kp.out + (size_t)cm0 * 2;
@@ -478,14 +523,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
 // PF: both k-substeps' fragments are read ahead of the first MFMA (40 more VGPRs; the second set lands while the first
 // set's MFMAs run).  Measured on one box against the read-as-you-go order: +3..11 % on the 3x3 layers, -4..8 % on the
 // short-K 1x1 layers, so the launcher picks it by kernel size.
-template <typename T, int MT, int NT, int WM, int WN, bool PF>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
+// STAGES: depth of the LDS tile ring.  2 = tile k+1 in flight while tile k feeds the MFMAs (two resident blocks per CU cover each other's
+// waits: the throughput configuration).  3 / 4 = two / three tiles in flight behind a COUNTED vmcnt: for launches whose grid leaves one
+// block per CU (the small per-GPU batches of a sharded search, MCTS groups, the 8x8 level), where a 2-deep ring makes every K step one
+// full L2 round trip (~2.1k cycles against 768 cycles of MFMAs).
+template <typename T, int MT, int NT, int WM, int WN, bool PF, int STAGES = 2>
+__global__ __launch_bounds__(256, (STAGES == 2 ? 2 : 1)) void conv_igemm_kernel(const ConvP kp) {
   const char* const p_x1 = kp.x1; const char* const p_x2 = kp.x2; const char* const p_w = kp.w;
   const int p_c1 = kp.c1, p_c2 = kp.c2, p_cin = kp.cin, p_hin = kp.hin, p_win = kp.win, p_hout = kp.hout, p_wout = kp.wout;
   const int p_taps = kp.taps, p_up = kp.up, p_P = kp.P, p_n_ct = kp.n_ct, p_n_pt = kp.n_pt;
   constexpr int NW = WM * WN;              // 4 waves per block, two blocks per CU (8-wave / 3-stage blocks with one block per
   static_assert(NW == 4, "4 waves");      // CU and persistent blocks were measured slower: profiles/r01_conv_variants.txt)
-  constexpr int STAGES = 2;                // LDS ring: tile k+1 in flight while tile k feeds the MFMAs
+  static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
   constexpr int SLAB = 8 * NW;             // rows staged by one wave-instruction round of the whole block
   constexpr int BM = 16 * MT * WM;         // couts per block
   constexpr int BN = 16 * NT * WN;         // pixels per block
@@ -497,6 +546,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
   static_assert(BM % SLAB == 0 && BN % SLAB == 0, "tile rows must split over the waves x 8 rows");
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  DTS_STAMP_RT(4);
+  DTS_STAMP(0);
 
   // ---- XCD-aware tile mapping: blocks b, b+8, b+16.. (same XCD under round-robin dispatch) walk the
   // cout tiles of one pixel tile consecutively, so the activation rows are re-read from that XCD's L2.
@@ -611,8 +662,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
     const uint32_t sb_ = wave_rows + A_BYTES;
     _Pragma("unroll") for (int j = 0; j < RB; ++j) glds16(brow[j], sb_ + j * SLAB * 128);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  constexpr int LPT = RA + RB;                         // LDS-DMA loads per wave and tile (vmcnt counts them in issue order)
+  if constexpr (STAGES > 2) {
+    // tiles 1 .. STAGES-2 go out behind the first; only tile 0 has to have landed before the loop starts
+    int ahead = 0;
+#pragma unroll
+    for (int q = 1; q < STAGES - 1; ++q)
+      if (ks_begin + q < ks_end) { ADVANCE_K(); ISSUE_TILE(q); ++ahead; }
+    if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __syncthreads();
+  DTS_STAMP(1);
 
   const int lrow = lane & 15, lq = lane >> 4;
   // early residual fetch (whole 16-bit tiles only: the ones that take conv_epilogue_fast)
@@ -638,16 +702,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
       for (int i = 0; i < MT; ++i) ga[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq + 4));
     }
     // the buffer written here was last read in iteration ks-1; every wave has passed that iteration's barrier
-    if (ks + 1 < ks_end) {
+    if (ks + STAGES - 1 < ks_end) {
       ADVANCE_K();
-      ISSUE_TILE(buf ^ 1);
-    } else if (res_early) {
-      // last K step: nothing left to prefetch, so the free ring buffer takes the residual pieces that fit it; they land
-      // under this step's MFMAs instead of an exposed fetch in the epilogue
-      stage_off = (buf ^ 1) == 0 ? 0 : (RING_BYTES - STAGED_BYTES);
-      const int free_lo = (buf ^ 1) * STAGE_BYTES - stage_off;                 // free buffer in staged-tile coordinates
-      early_u0 = max(0, (free_lo + PIECE - 1) / PIECE);
-      early_u1 = min(PIECES, (free_lo + STAGE_BYTES) / PIECE);
+      int wr = buf + STAGES - 1;
+      if (wr >= STAGES) wr -= STAGES;
+      ISSUE_TILE(wr);
+    } else if (res_early && ks + 1 == ks_end) {
+      // last K step: nothing is in flight any more and every ring buffer but `buf` is free, so the larger free side of the ring takes
+      // the residual pieces that fit it; they land under this step's MFMAs instead of an exposed fetch in the epilogue
+      const int lo_free = buf * STAGE_BYTES, hi_free = (STAGES - 1 - buf) * STAGE_BYTES;      // bytes below / above the buffer being read
+      int f0, f1;                                                                             // the free interval used (ring coordinates)
+      if (lo_free >= hi_free) { f0 = 0; f1 = lo_free; stage_off = 0; }
+      else { f0 = (buf + 1) * STAGE_BYTES; f1 = RING_BYTES; stage_off = min(f0, RING_BYTES - STAGED_BYTES); }
+      early_u0 = max(0, (f0 - stage_off + PIECE - 1) / PIECE);
+      early_u1 = min(PIECES, max(0, (f1 - stage_off) / PIECE));
+      if (early_u1 < early_u0) early_u1 = early_u0;
       issue_residual_pieces<BM, 64 * NW>(kp, cm0, linear_tile(pn0), lds_base + stage_off, tid, early_u0, early_u1);
     }
     __builtin_amdgcn_s_setprio(1);
@@ -668,14 +737,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP kp) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], ga[i], gb[j]);
     __builtin_amdgcn_s_setprio(0);
-    // next tile has landed (LDS-DMA completion is tracked by vmcnt) and this wave's LDS reads of the current tile have
-    // returned
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // next tile has landed (LDS-DMA completion is tracked by vmcnt, in issue order: the tiles issued after it may still fly) and
+    // this wave's LDS reads of the current tile have returned
+    if constexpr (STAGES > 2) {
+      const int later = min(STAGES - 2, ks_end - 2 - ks);                  // tiles issued beyond tile ks+1 (wave-uniform)
+      if (later >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * LPT) : "memory");
+      else if (later == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LPT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
     __syncthreads();
-    buf ^= 1;
+    if (++buf == STAGES) buf = 0;
   }
 
+  DTS_STAMP(2);
   conv_epilogue<T, MT, NT, BM, BN>(kp, acc, cm0, linear_tile(pn0), (int)blockIdx.y, wm, wn, lrow, lq, smem, bias_in_acc, stage_off, early_u0, early_u1);
+  DTS_STAMP(3);
+  DTS_STAMP_RT(5);
 }
 #undef SET_ROWS
 #undef ISSUE_TILE
@@ -747,6 +826,8 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
   constexpr int BKE = 64, ES = 2;
   constexpr int A_HALF = GM * 128, A_RING = 3 * A_HALF, H_OFF = 2 * A_RING, H_BUF = 328 * 128;       // see the LDS map above
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  DTS_STAMP_RT(4);
+  DTS_STAMP(0);
   const char* const p_x1 = kp.x1; const char* const p_x2 = kp.x2; const char* const p_w = kp.w;
   // W, H: OUTPUT image size (= input size, or twice it when the nearest-2x upsample of the input is fused into the halo gather)
   const int p_c1 = kp.c1, p_c2 = kp.c2, p_cin = kp.cin, W = kp.wout, H = kp.hout, Wi = kp.win, Hi = kp.hin, ups = kp.up ? 1 : 0;
@@ -914,8 +995,11 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   asm volatile("s_barrier" ::: "memory");
+  DTS_STAMP(1);
   if (grp == 1) asm volatile("s_barrier" ::: "memory");          // the stagger: group 1 runs one segment behind group 0
 
+  DTS_SEG_DECL
+  DTS_SEG_START
   int t = 0;                                             // K tile index inside this block's range
   uint32_t a_rd = grp * A_RING;                          // read slot of this group's A ring (byte offset)
   uint32_t h_rd = H_OFF;                                 // halo buffer being read (byte offset)
@@ -985,6 +1069,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
           }
         }
       }
+      DTS_SEG_MARK(0)                                      // section 0: barrier exit -> all LDS-DMA pieces issued
       if constexpr (LOAD_ORDER == 2) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1000,9 +1085,11 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
       for (int i = 0; i < MT; ++i) ga[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq + 4));
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every fragment is in registers: slots / buffers may be refilled
+      DTS_SEG_MARK(1)                                      // section 1: fragment reads issued and returned
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_barrier" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
+      DTS_SEG_MARK(2)                                      // section 2: wait in the barrier that ends LOAD
       // ---------------- COMPUTE(t)
       __builtin_amdgcn_s_setprio(1);
       if constexpr (DBG == 2) {
@@ -1054,6 +1141,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
       }
       __builtin_amdgcn_s_setprio(0);
       if constexpr (fuse_gn) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the normalised piece is in LDS
+      DTS_SEG_MARK(3)                                      // section 3: the MFMAs (issue; the last ones still drain)
       __builtin_amdgcn_sched_barrier(0);
       // everything issued before LOAD(t) has landed -- A_g(t+1), the older halo pieces; only LOAD(t)'s own pieces may fly on
       if (inflight == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -1061,8 +1149,10 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
       else if (inflight == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       else if (inflight == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      DTS_SEG_MARK(4)                                      // section 4: counted vmcnt wait
       asm volatile("s_barrier" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
+      DTS_SEG_MARK(5)                                      // section 5: wait in the barrier that ends COMPUTE
       ++t;
       a_rd = (a_rd == grp * A_RING + 2 * A_HALF) ? grp * A_RING : a_rd + A_HALF;
     }
@@ -1070,6 +1160,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
     h_rd = (h_rd == H_OFF) ? H_OFF + H_BUF : H_OFF;
   }
   if (grp == 0) asm volatile("s_barrier" ::: "memory");          // matches group 1's last COMPUTE barrier
+  DTS_SEG_STORE
 #undef PP_SET_SRC
 #undef PP_ISSUE_A
 #undef PP_ISSUE_A_PIECES
@@ -1077,25 +1168,34 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
 #undef PP_LOAD_COEF
 #undef PP_GN_PIECE
   __syncthreads();
+  DTS_STAMP(2);
 
   conv_epilogue<T, MT, NT, BM, BN, NTHR>(kp, acc, cm0, tm, (int)blockIdx.y, wm, wn, lrow, lq, smem, bias_in_acc, 0, 0, 0);
+  DTS_STAMP(3);
+  DTS_STAMP_RT(5);
 }
 
-// split-K second pass: fixed-order sum of the f32 slabs + the conv epilogue
-template <typename T>
+// split-K second pass: fixed-order sum of the f32 slabs + the conv epilogue.
+// SPLITS is a template parameter so that ALL slab loads of an element are in flight at once: with a run-time trip count hipcc emits
+// one load + wait per split, i.e. `splits` dependent L2 round trips per element -- 8 us for a 12 MB reduce that moves 3 us of bytes
+// (tools/conv_stamps.py: the 8x8-level launches spent more time in this pass and its gaps than in their conv kernel).
+template <typename T, int SPLITS>
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvP kp) {
   const long long total = (long long)kp.P * (kp.cout / 4);
   const T* res = reinterpret_cast<const T*>(kp.residual);
   const T* bnc = reinterpret_cast<const T*>(kp.bias_nc);
   T* out = reinterpret_cast<T*>(kp.out);
   const int hw = kp.hout * kp.wout, c4 = kp.cout / 4;
+  const size_t slab = (size_t)kp.P * kp.cout;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int pp = (int)(idx / c4), co = (int)(idx - (long long)pp * c4) * 4;
+    const float* base = kp.partial + (size_t)pp * kp.cout + co;
+    float4 q[SPLITS];
+#pragma unroll
+    for (int s = 0; s < SPLITS; ++s) q[s] = *reinterpret_cast<const float4*>(base + (size_t)s * slab);
     float v[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < kp.splits; ++s) {
-      const float4 q = *reinterpret_cast<const float4*>(kp.partial + ((size_t)s * kp.P + pp) * kp.cout + co);
-      v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
-    }
+#pragma unroll
+    for (int s = 0; s < SPLITS; ++s) { v[0] += q[s].x; v[1] += q[s].y; v[2] += q[s].z; v[3] += q[s].w; }      // fixed order
     if (kp.bias) {
       const float4 bv = *reinterpret_cast<const float4*>(kp.bias + co);
       v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
@@ -1120,7 +1220,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvP kp)
 // costs two more passes (gn_partial + gn_coef): at the 8-candidates-per-GPU batch of a sharded search those were 2.6 ms of a
 // 15.9 ms iteration.  Block = one strip x 64 channels, then a fixed-order LDS reduction over the sixteen pixel lanes
 // (deterministic, no atomics).  Same arithmetic and order per element as conv_splitk_reduce_kernel.
-template <typename T>
+template <typename T, int SPLITS>
 __global__ __launch_bounds__(256) void conv_splitk_reduce_stats_kernel(const ConvP kp) {
   // thread = 4 channels x 4 pixels (pixel lane pl, pixels pl + 16 i of the strip): 16 quads x 16 B = one 256-byte segment per
   // pixel row, four independent load chains per thread over the splits
@@ -1138,13 +1238,18 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_stats_kernel(const Con
     float v[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f; }
-    for (int s_ = 0; s_ < kp.splits; ++s_) {             // fixed order over the splits (as conv_splitk_reduce_kernel)
-      const float* base = kp.partial + ((size_t)s_ * kp.P + p0) * kp.cout + co;
+    {                                                    // every slab load of the thread in flight at once (SPLITS x 4)
+      const float* base = kp.partial + (size_t)p0 * kp.cout + co;
+      const size_t slab = (size_t)kp.P * kp.cout;
+      float4 t4[SPLITS][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float4 t4 = *reinterpret_cast<const float4*>(base + (size_t)(16 * i) * kp.cout);
-        v[i][0] += t4.x; v[i][1] += t4.y; v[i][2] += t4.z; v[i][3] += t4.w;
-      }
+      for (int s_ = 0; s_ < SPLITS; ++s_)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t4[s_][i] = *reinterpret_cast<const float4*>(base + (size_t)s_ * slab + (size_t)(16 * i) * kp.cout);
+#pragma unroll
+      for (int s_ = 0; s_ < SPLITS; ++s_)                // fixed order over the splits (as conv_splitk_reduce_kernel)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i][0] += t4[s_][i].x; v[i][1] += t4[s_][i].y; v[i][2] += t4[s_][i].z; v[i][3] += t4[s_][i].w; }
     }
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (kp.bias) bv = *reinterpret_cast<const float4*>(kp.bias + co);
@@ -1183,9 +1288,63 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_stats_kernel(const Con
   }
 }
 
+constexpr int DTS_MAX_DEVICES = 64;
+inline int current_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= DTS_MAX_DEVICES) d = 0;
+  return d;
+}
+
+// launches the split-K second pass (with the strip statistics when `stats_req` is set and the shape allows)
+template <typename T, int SPLITS>
+int launch_reduce_n(const ConvP& q, bool with_stats, hipStream_t st) {
+  if (with_stats) {
+    hipLaunchKernelGGL((conv_splitk_reduce_stats_kernel<T, SPLITS>), dim3(q.P / 64, (q.cout + 63) / 64), dim3(256), 0, st, q);
+    DTS_CHECK_LAUNCH("dts_conv2d(split-K reduce + statistics)");
+  } else {
+    long long g = ((long long)q.P * (q.cout / 4) + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL((conv_splitk_reduce_kernel<T, SPLITS>), dim3((int)g), dim3(256), 0, st, q);
+    DTS_CHECK_LAUNCH("dts_conv2d(split-K reduce)");
+  }
+  return DTS_OK;
+}
+template <typename T>
+int launch_reduce(const ConvP& q, bool with_stats, hipStream_t st) {
+  switch (q.splits) {
+    case 2: return launch_reduce_n<T, 2>(q, with_stats, st);
+    case 3: return launch_reduce_n<T, 3>(q, with_stats, st);
+    case 4: return launch_reduce_n<T, 4>(q, with_stats, st);
+    case 5: return launch_reduce_n<T, 5>(q, with_stats, st);
+    case 6: return launch_reduce_n<T, 6>(q, with_stats, st);
+    case 7: return launch_reduce_n<T, 7>(q, with_stats, st);
+    case 8: return launch_reduce_n<T, 8>(q, with_stats, st);
+    default: dts_set_error("dts_conv2d: split-K factor %d outside 2..8", q.splits); return DTS_ERR_ARG;
+  }
+}
+
+template <typename T, int MT, int NT, int WM, int WN, bool PF, int STAGES>
+int launch_conv_staged(const ConvP& q, int nblk, int splits, hipStream_t st, ConvCall& call) {
+  constexpr int NW = WM * WN;
+  constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
+  const size_t lds = (size_t)STAGES * (BM + BN) * 128;
+  static bool attr_done[DTS_MAX_DEVICES] = {};            // the attribute is per DEVICE: a process that drives several GPUs sets it on each
+  const int dev = current_device();
+  if (!attr_done[dev]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, MT, NT, WM, WN, PF, STAGES>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done[dev] = true;
+  }
+  if (call.ev_start != nullptr && call.ev_stop != nullptr)
+    hipExtLaunchKernelGGL((conv_igemm_kernel<T, MT, NT, WM, WN, PF, STAGES>), dim3(nblk, splits), dim3(64 * NW), lds, st, call.ev_start, call.ev_stop, 0, q);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<T, MT, NT, WM, WN, PF, STAGES>), dim3(nblk, splits), dim3(64 * NW), lds, st, q);
+  DTS_CHECK_LAUNCH("dts_conv2d");
+  return DTS_OK;
+}
+
 template <typename T, int MT, int NT, int WM, int WN, bool PF>
 int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, ConvCall& call) {
-  constexpr int NW = WM * WN;
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
   constexpr int BKE = 8 * ET<T>::EPV;
   ConvP q = p;
@@ -1202,6 +1361,22 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, C
     if (splits > nk / 8) splits = nk / 8;
     while (splits > 1 && (long long)splits * p.P * p.cout * 4 > ws_bytes) --splits;
     if (splits < 1) splits = 1;
+    // the second pass moves `splits` f32 slabs of P x cout: for many-pixel layers at a small batch it costs more than the shorter K loop
+    // saves.  Estimated microseconds (tools/conv_stamps.py): ~5.5 us of prologue + epilogue and ~0.95 us per K step per round of
+    // resident blocks; reduce = ~3 us + slab bytes at ~4 MB/us.
+    if (splits > 1) {
+      auto est = [&](int s_) {
+        const int steps = (nk + s_ - 1) / s_;
+        const double rounds = (double)((nblk * s_ + slots - 1) / slots);
+        double t = rounds * (5.5 + steps * 0.95);
+        if (s_ > 1) t += 3.0 + (s_ + 0.5) * (double)p.P * p.cout * 4.0 / 4.0e6;
+        return t;
+      };
+      int best = 1;
+      for (int s_ = 2; s_ <= splits; ++s_)
+        if (est(s_) < est(best)) best = s_;
+      splits = best;
+    }
   }
   q.ks_per_split = (nk + splits - 1) / splits;
   splits = (nk + q.ks_per_split - 1) / q.ks_per_split;       // no empty split
@@ -1212,34 +1387,30 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, C
   const bool stats_in_reduce = splits > 1 && stats_req != nullptr && (p.hout * p.wout) % 64 == 0 && p.cout % 4 == 0;
   if (splits > 1 || NT != 4) q.stats = nullptr;
   call.stats_written = q.stats != nullptr || stats_in_reduce;
-  const size_t lds = (size_t)2 * (BM + BN) * 128;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, MT, NT, WM, WN, PF>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
-  if (call.ev_start != nullptr && call.ev_stop != nullptr)
-    hipExtLaunchKernelGGL((conv_igemm_kernel<T, MT, NT, WM, WN, PF>), dim3(nblk, splits), dim3(64 * NW), lds, st, call.ev_start, call.ev_stop, 0, q);
-  else
-    hipLaunchKernelGGL((conv_igemm_kernel<T, MT, NT, WM, WN, PF>), dim3(nblk, splits), dim3(64 * NW), lds, st, q);
-  DTS_CHECK_LAUNCH("dts_conv2d");
-  if (splits > 1 && stats_in_reduce) {
-    q.stats = stats_req;
-    hipLaunchKernelGGL((conv_splitk_reduce_stats_kernel<T>), dim3(p.P / 64, (p.cout + 63) / 64), dim3(256), 0, st, q);
-    DTS_CHECK_LAUNCH("dts_conv2d(split-K reduce + statistics)");
-  } else if (splits > 1) {
-    long long g = ((long long)p.P * (p.cout / 4) + 255) / 256;
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL((conv_splitk_reduce_kernel<T>), dim3((int)g), dim3(256), 0, st, q);
-    DTS_CHECK_LAUNCH("dts_conv2d(split-K reduce)");
+  // ring depth: a grid of at most one block per CU cannot hide a tile's round trip behind a co-resident block, so it keeps two
+  // tiles in flight (3 stages; DTS_CONV_STAGES = 2 | 3 | 4 forces a depth for A/B runs)
+  int stages = ((long long)nblk * splits <= 256 && q.ks_per_split >= 3) ? 3 : 2;
+  const int forced_stages = dts_knob_get(DTS_KNOB_CONV_STAGES);
+  if (forced_stages >= 2 && forced_stages <= 4) stages = forced_stages;
+  if (std::is_same<T, float>::value) stages = 2;            // parity mode: one configuration
+  if ((size_t)stages * (BM + BN) * 128 > 160 * 1024) stages = 3;
+  int rc;
+  if (stages == 4) rc = launch_conv_staged<T, MT, NT, WM, WN, PF, (sizeof(T) == 2 ? 4 : 2)>(q, nblk, splits, st, call);
+  else if (stages == 3) rc = launch_conv_staged<T, MT, NT, WM, WN, PF, (sizeof(T) == 2 ? 3 : 2)>(q, nblk, splits, st, call);
+  else rc = launch_conv_staged<T, MT, NT, WM, WN, PF, 2>(q, nblk, splits, st, call);
+  if (rc != DTS_OK) return rc;
+  if (splits > 1) {
+    if (stats_in_reduce) q.stats = stats_req;
+    return launch_reduce<T>(q, stats_in_reduce, st);
   }
   return DTS_OK;
 }
 
-// ---- ping-pong launcher: one block per (192-cout tile, 256-pixel tile[, K split]); 512 threads, 136 KB of LDS
+// ---- ping-pong launcher: one block per (192- or 128-cout tile, 256-pixel tile[, K split]); 512 threads, 154 KB (MT = 6) / 130 KB (MT = 4) of LDS
 template <typename T, int TAPS, int DBG = 0, bool GN = false, int MT = 6>
 int launch_conv_pp(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, ConvCall& call) {
+  // 3x3 only: the kernel's TAPS == 1 form has a landing race with more than one channel chunk (see conv_pick_pp) and must not be launched
+  static_assert(TAPS == 9, "conv_pp_kernel: only the 3x3 form is safe to launch");
   if constexpr (sizeof(T) != 2) {
     return DTS_ERR_UNSUPPORTED;
   } else {
@@ -1253,9 +1424,23 @@ int launch_conv_pp(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes
     const int forced = dts_knob_get(DTS_KNOB_CONV_SPLITS);
     if (ws != nullptr && nk >= 16) {
       if (forced > 0) splits = forced;
-      else if (nblk < 192) splits = (256 + nblk - 1) / nblk;     // one resident block per CU: fill 256 slots
+      else if (nblk < 192) {
+        // One resident block per CU.  Splitting K fills idle CUs but pays a second pass over `splits` f32 slabs of P x cout, which for
+        // the many-pixel layers of a SMALL batch costs more than it saves (64x64 level at 8 rows: 2 x 25 MB of slabs for a 10 us
+        // shorter K loop -- tools/conv_stamps.py).  Estimated microseconds, from the in-kernel stamps: ~5 us of prologue + epilogue,
+        // ~1.05 us per K tile (two ~1050-cycle segments), reduce = ~3 us + slab bytes at ~4 MB/us.
+        const int nchunk = nk / TAPS;
+        double best = 1e30;
+        for (int s_ = 1; s_ <= 8 && s_ <= nchunk; ++s_) {
+          const int cps = (nchunk + s_ - 1) / s_, se = (nchunk + cps - 1) / cps;
+          if (se != s_ || nblk * se > 256) continue;
+          double t = 5.0 + cps * TAPS * 1.05;
+          if (se > 1) t += 3.0 + (se + 0.5) * (double)p.P * p.cout * 4.0 / 4.0e6;
+          if (t < best) { best = t; splits = se; }
+        }
+      }
       if (splits > 8) splits = 8;
-      if (splits > nk / 8) splits = nk / 8;
+      if (forced > 0 && splits > nk / 8) splits = nk / 8;
       if (splits > nk / TAPS) splits = nk / TAPS;
       while (splits > 1 && (long long)splits * p.P * p.cout * 4 > ws_bytes) --splits;
       if (splits < 1) splits = 1;
@@ -1273,25 +1458,20 @@ int launch_conv_pp(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes
     if (splits > 1) q.stats = nullptr;
     call.stats_written = q.stats != nullptr || stats_in_reduce;
     constexpr size_t lds = (size_t)(6 * 16 * MT + 2 * 328) * 128;      // A: 2 groups x 3 slots x 16*MT rows; halo: 2 buffers x 328 rows
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[DTS_MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (!attr_done[dev]) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<T, TAPS, DBG, GN, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_done = true;
+      attr_done[dev] = true;
     }
     if (call.ev_start != nullptr && call.ev_stop != nullptr)
       hipExtLaunchKernelGGL((conv_pp_kernel<T, TAPS, DBG, GN, MT>), dim3(nblk, splits), dim3(512), lds, st, call.ev_start, call.ev_stop, 0, q);
     else
       hipLaunchKernelGGL((conv_pp_kernel<T, TAPS, DBG, GN, MT>), dim3(nblk, splits), dim3(512), lds, st, q);
     DTS_CHECK_LAUNCH("dts_conv2d(ping-pong)");
-    if (splits > 1 && stats_in_reduce) {
-      q.stats = stats_req;
-      hipLaunchKernelGGL((conv_splitk_reduce_stats_kernel<T>), dim3(p.P / 64, (p.cout + 63) / 64), dim3(256), 0, st, q);
-      DTS_CHECK_LAUNCH("dts_conv2d(split-K reduce + statistics)");
-    } else if (splits > 1) {
-      long long g = ((long long)p.P * (p.cout / 4) + 255) / 256;
-      if (g > 2048) g = 2048;
-      hipLaunchKernelGGL((conv_splitk_reduce_kernel<T>), dim3((int)g), dim3(256), 0, st, q);
-      DTS_CHECK_LAUNCH("dts_conv2d(split-K reduce)");
+    if (splits > 1) {
+      if (stats_in_reduce) q.stats = stats_req;
+      return launch_reduce<T>(q, stats_in_reduce, st);
     }
     return DTS_OK;
   }
@@ -1351,13 +1531,20 @@ int conv_dispatch(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes,
     const int variant = dts_knob_get(DTS_KNOB_CONV_VARIANT);
 #define DTS_PP(DBG_) launch_conv_pp<T, 9, DBG_>(p, st, ws, ws_bytes, call)
     if (p.gn_coef != nullptr) return launch_conv_pp<T, 9, 0, true>(p, st, ws, ws_bytes, call);
-    if (variant == 11) return DTS_PP(1);     // timing-only diagnostics
+#ifdef DTS_DIAG_KERNELS      // diagnostic builds only (tools/conv_stamps.py --diag): 11/21/41/51 are TIMING-ONLY (outputs wrong by construction)
+    if (variant == 11) return DTS_PP(1);
     if (variant == 21) return DTS_PP(2);
     if (variant == 41) return DTS_PP(4);
     if (variant == 51) return DTS_PP(5);
     if (variant == 61) return DTS_PP(6);     // LOAD-order A/B builds (correct outputs)
     if (variant == 71) return DTS_PP(7);
     if (variant == 81) return DTS_PP(8);     // weight pieces split between LOAD and COMPUTE (measured slower)
+#else
+    if (variant > 1) {
+      dts_set_error("dts_conv2d: DTS_CONV_VARIANT=%d selects a diagnostic kernel that this library was built without (-DDTS_DIAG_KERNELS)", variant);
+      return DTS_ERR_ARG;
+    }
+#endif
     return DTS_PP(0);
 #undef DTS_PP
   }
@@ -1381,6 +1568,22 @@ void conv_shape_from_args(const dts_conv_args* a, ConvP& p) {
 }
 
 }  // namespace
+
+#ifdef DTS_STAMPS
+extern "C" int dts_debug_read_stamps(unsigned long long* host, int count) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (size_t)count);
+}
+extern "C" int dts_debug_clear_stamps(void) {
+  void* p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_stamps)) != hipSuccess) return -1;
+  if (hipMemset(p, 0, sizeof(g_stamps)) != hipSuccess) return -1;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_seg)) != hipSuccess) return -1;
+  return (int)hipMemset(p, 0, sizeof(g_seg));
+}
+extern "C" int dts_debug_read_segments(unsigned long long* host, int count) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_seg), sizeof(unsigned long long) * (size_t)count);
+}
+#endif
 
 extern "C" int dts_conv_kernel(const dts_conv_args* a) {
   if (a == nullptr || (a->ksize != 1 && a->ksize != 3) || a->n <= 0 || a->hin <= 0 || a->win <= 0 || a->cout <= 0) return -1;

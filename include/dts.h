@@ -35,7 +35,8 @@ enum dts_status { DTS_OK = 0, DTS_ERR_ARG = -1, DTS_ERR_LAUNCH = -2, DTS_ERR_UNS
                                      head dim 512 in dts_attention; 106: dts_conv_kernel, 128-cout ping-pong blocks) */
 int dts_version(void);            /* == DTS_ABI_VERSION of the build; a binding must refuse any other value */
 const char* dts_last_error(void);
-/* Tuning knobs (measurement aid; a knob only selects between kernels / block orders with identical results).  knob: index of
+/* Tuning knobs (measurement aid; a knob only selects between kernels / block orders / ring depths that give correct results -- the
+ * timing-only diagnostic kernels exist only in builds made with -DDTS_DIAG_KERNELS and are refused by the product library).  knob: index of
  * enum dts_knob in csrc/dts_common.h; value -1 = launcher default.  Used by tools/conv_bench.py and tools/att_bench.py to A/B variants in one process. */
 int dts_set_tuning(int knob, int value);
 int dts_get_tuning(int knob);
@@ -72,8 +73,8 @@ typedef struct dts_conv_args {
   int64_t workspace_bytes;
   float* stats_out;               /* optional [ceil(P/64)][cout][2] f32: per 64-pixel strip (sum, sumsq) of the stored outputs,
                                      the GroupNorm moments of the NEXT layer fused into this epilogue (needs hout*wout % 64 == 0) */
-  int32_t stats_written;          /* OUT: 1 if stats_out was filled (0 when the launch took the split-K path: fall back to dts_gn_coef); split-K launches
-                                     emit the statistics from their reduce pass */
+  int32_t stats_written;          /* OUT: 1 whenever stats_out was filled -- by the fused epilogue, or by the reduce pass of a split-K launch;
+                                     0: the statistics were not produced (tile variant without 64-pixel wave strips): run dts_gn_coef */
   void* ev_start; void* ev_stop;  /* optional hipEvent_t pair attached to the conv kernel's own dispatch (start / end of that kernel, as a
                                      kernel trace sees it; no barrier packets between launches).  Measurement only: bench.py's roofline leg */
   const float* gn_coef;           /* optional [n][c1+c2][2] f32 (a, b) from dts_gn_coef / dts_gn_coef_strips: the GroupNorm (+ adaptive
@@ -160,9 +161,9 @@ int dts_heun_correct(const double* x_hat, const float* D2, const double* d_cur, 
 int dts_quantize_u8(const void* x, int is_f32, uint8_t* out, int64_t count, dts_stream s);
 /* rewards[n] = clamp(mean_hw(0.2126 R + 0.7152 G + 0.0722 B)/1, 0, 1) on u8/255 images NCHW [n][3][h][w] */
 int dts_brightness(const uint8_t* img, float* rewards, int n, int hw, dts_stream s);
-/* f32 NCHW = u8 / 255.0f (scorers.py:153) */
 /* CLIP reward tail (sd/scorers.py:182-183,205-211): out[i] = <a_i/||a_i||, b_i/||b_i||>, f32; b has n rows or 1 (one prompt). */
 int dts_cosine_rows(const float* a, const float* b, int b_rows, float* out, int n, int d, dts_stream s);
+/* f32 NCHW = u8 / 255.0f (scorers.py:153) */
 int dts_u8_to_unit_f32(const uint8_t* img, float* out, int64_t count, dts_stream s);
 
 /* ---- K12 tail: attention pool + softmax-gather (unet.py:61-69; scorers.py:162-172) ---------------- */

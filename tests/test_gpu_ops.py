@@ -254,6 +254,58 @@ def test_ping_pong_conv_kernel_on_every_kind_of_shape(ops, dtype, n, res, c1, c2
         assert rel_err(got._gn_stats.reshape(n, -1, cout, 2).sum(1).cpu(), want.cpu()) < 1e-5
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('variant', ['ping_pong', 'ring3'])
+def test_conv_kernels_with_hand_counted_waits_repeat_bit_for_bit(ops, dtype, variant):
+    """Race screen inside the suite (was tools/pp_stress.py): the kernels whose LDS-DMA loads are awaited by hand-counted `vmcnt` --
+    conv_pp_kernel (forced on every eligible shape) and conv_igemm_kernel with its 3-deep ring -- launched 12 times per shape with the
+    caches / clocks disturbed in between: every launch reproduces the first one bit for bit (outputs AND strip statistics) and sits
+    within one output ulp of the f32 parity kernel.  Shapes: the classes of test_ping_pong_conv_kernel_on_every_kind_of_shape at the
+    sizes of a sharded search (residual, concat, split-K, 192- and 128-cout blocks, 8x8 level, 1x1)."""
+    from diffusion_tts_amd import _lib
+    torch.manual_seed(1)
+    shapes = [  # n, res, c1, c2, cout, ksize, residual
+        (8, 64, 192, 0, 192, 3, True), (8, 32, 384, 384, 384, 3, False), (16, 16, 576, 0, 576, 3, True), (8, 16, 576, 768, 576, 3, False),
+        (8, 32, 256, 0, 256, 3, False), (8, 64, 128, 0, 128, 3, False), (8, 16, 1152, 0, 576, 3, False), (16, 32, 192, 0, 384, 3, False),
+    ]
+    if variant == 'ring3':   # the 4-wave kernel's small-grid launches: 8x8 level (split-K), 1x1 layers, 16x16 level
+        shapes = [(8, 8, 768, 0, 768, 3, True), (8, 8, 768, 768, 768, 3, False), (8, 8, 768, 0, 2304, 1, False), (8, 16, 576, 0, 576, 1, True),
+                  (8, 16, 576, 0, 1728, 1, False), (16, 8, 512, 0, 512, 3, True), (8, 16, 576, 0, 576, 3, True), (2, 32, 384, 0, 1152, 1, False)]
+    knob, val = ('conv_variant', 1) if variant == 'ping_pong' else ('conv_stages', 3)
+    trash = torch.empty(32 << 20, device=DEV, dtype=torch.float32)
+    for (n, res, c1, c2, cout, ks, use_res) in shapes:
+        x1 = torch.randn(n, res, res, c1, device=DEV).to(dtype)
+        x2 = torch.randn(n, res, res, c2, device=DEV).to(dtype) if c2 else None
+        C_ = c1 + c2
+        w = (torch.randn(cout, ks, ks, C_, device=DEV) / math.sqrt(ks * ks * C_)).to(dtype)
+        b = torch.randn(cout, device=DEV)
+        r = torch.randn(n, res, res, cout, device=DEV).to(dtype) if use_res else None
+        _lib.set_tuning(knob, val)
+        try:
+            if variant == 'ping_pong':
+                assert ops.conv_kernel(x1, w, x2=x2, residual=r) in (4, 6)
+            first = first_st = None
+            for rep in range(12):
+                if rep % 3 == 1:
+                    trash.normal_()                       # evict L2 / MALL, change what the memory system is doing
+                if rep % 3 == 2:
+                    torch.cuda.synchronize()
+                    torch.cuda._sleep(2_000_000)
+                o = ops.conv2d(x1, w, b, x2=x2, residual=r, out_scale=0.9, gn_stats=True)
+                st = o._gn_stats
+                if first is None:
+                    first, first_st = o.clone(), (None if st is None else st.clone())
+                else:
+                    assert torch.equal(o, first), (variant, n, res, c1, c2, cout, ks, rep)
+                    assert st is None or torch.equal(st, first_st), (variant, n, res, c1, c2, cout, ks, rep)
+        finally:
+            _lib.set_tuning(knob, -1)
+        ref = ops.conv2d(x1.float(), w.float(), b, x2=None if x2 is None else x2.float(), residual=None if r is None else r.float(),
+                         out_scale=0.9)
+        ulp = float(ref.abs().max()) * (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11)
+        assert float((first.float() - ref).abs().max()) <= 1.01 * ulp, (variant, n, res, c1, c2, cout, ks)
+
+
 def test_conv2d_identical_rows_are_bit_identical(ops):
     """ties must stay ties: the same candidate at different batch positions gives the same bits."""
     gen = g(2)
