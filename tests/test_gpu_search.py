@@ -153,9 +153,24 @@ def test_search_throughput_modes_stay_close(pkg, golden, manifest, dtype):
     err = (res['x'].cpu() - ref_x).abs().max().item()
     assert np.isfinite(err) and err < (0.05 if dtype == torch.float16 else 0.25), err
     meta, res = run_case(pkg, golden, manifest, 'epsgreedy_adm_bright', dtype)
-    agree = np.mean([np.array_equal(sel.numpy(), golden[f'epsgreedy_adm_bright_score{j}'].reshape(4, 2).argmax(axis=0))
-                     for j, sel in enumerate(res['selected'])])
-    assert agree >= 0.5, agree
+    # free-running search (a differing pick changes everything after it), brightness rewards: every selection is compared with the
+    # reference's as long as the two searches have made the same picks so far (same state: the reward deviation measured there is the
+    # mode's own noise), and only where the reference's top-2 gap is decidable at that noise (> 4 x the deviation)
+    same_so_far, checked = True, 0
+    for j, sel in enumerate(res['selected']):
+        ref = golden[f'epsgreedy_adm_bright_score{j}'].reshape(4, 2)
+        if not same_so_far:
+            break
+        dev = np.abs(res['rewards'][j].reshape(4, 2).float().numpy() - ref).max()
+        assert dev < 5e-3, (j, dev)                        # a brightness mean over 16x16x3 pixels: 16-bit trajectories stay this close
+        srt = np.sort(ref, axis=0)
+        decidable = (srt[-1] - srt[-2]) > 4 * dev
+        mine_sel, ref_sel = sel.numpy(), ref.argmax(axis=0)
+        assert np.array_equal(mine_sel[decidable], ref_sel[decidable]), (j, mine_sel, ref_sel, srt[-1] - srt[-2], dev)
+        checked += int(decidable.sum())
+        same_so_far = np.array_equal(mine_sel, ref_sel)
+    print(f'{dtype}: {checked} decidable selections checked before the first differing pick')
+    assert checked >= 4
 
 
 def test_reusing_the_winners_row_changes_nothing(pkg, golden, manifest):
