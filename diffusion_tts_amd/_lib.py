@@ -52,6 +52,8 @@ SIGNATURES = {
     'dts_quantize_u8': [_p, _i, _p, _i64, _p],
     'dts_brightness': [_p, _p, _i, _i, _p],
     'dts_u8_to_unit_f32': [_p, _p, _i64, _p],
+    'dts_resample_u8': [_p, _p, _i, _i, _i, _i, _i, _p, _p, _i, _p],
+    'dts_lut_u8_f32': [_p, _p, _p, _i, _i, _i, _p],
     'dts_cosine_rows': [_p, _p, _i, _p, _i, _i, _p],
     'dts_attnpool_tokens': [_p, _p, _p, _i, _i, _i, _i, _p],
     'dts_take_token': [_p, _i, _p, _i, _i, _i, _i, _p],
@@ -63,7 +65,7 @@ SIGNATURES = {
 OTHER = {'dts_version': ([], _i), 'dts_conv_fuses_gn': ([C.POINTER(ConvArgs)], _i), 'dts_conv_kernel': ([C.POINTER(ConvArgs)], _i), 'dts_set_tuning': ([_i, _i], _i), 'dts_get_tuning': ([_i], _i), 'dts_last_error': ([], C.c_char_p), 'dts_gn_ws_floats': ([_i, _i], _i64)}
 
 _lib = None
-ABI_VERSION = 106              # include/dts.h DTS_ABI_VERSION this binding was written against (ConvArgs = 176 bytes)
+ABI_VERSION = 107              # include/dts.h DTS_ABI_VERSION this binding was written against (ConvArgs = 176 bytes)
 
 
 def load():

@@ -186,6 +186,46 @@ __global__ void cfg_combine_kernel(const T* __restrict__ u, const T* __restrict_
   }
 }
 // one block per image; u8/255 in f32, weighted channel sum in f32 (as the reference), spatial mean in f64
+// ---- CLIP image pre-processing on the device (sd/scorers.py:166-180 -> transformers CLIPImageProcessor -> Pillow) ----------------
+// One pass of Pillow's separable 8-bit resampling (src/libImaging/Resample.c, ImagingResampleHorizontal_8bpc / Vertical_8bpc): every
+// output sample is  clip8((2^(P-1) + sum_k src[first + k] * coef[k]) >> P)  with P = 22 and the integer coefficients Pillow derives
+// from its double-precision filter weights (built on the host, clip_preprocess.py: the table IS Pillow's).  Integer arithmetic end to
+// end, so the result is Pillow's bit for bit.  axis 1: along a row ([planes][h][w] -> [planes][h][out_len]); axis 0: down a column
+// ([planes][h][w] -> [planes][out_len][w]).  bounds[o] = (first, count), coefs[o][ksize].
+__global__ __launch_bounds__(256) void resample_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int planes, int h, int w,
+                                                           int out_len, int axis, const int* __restrict__ bounds,
+                                                           const int* __restrict__ coefs, int ksize) {
+  const long long total = axis ? (long long)planes * h * out_len : (long long)planes * out_len * w;
+  GSL(i, total) {
+    int o, first, cnt;
+    long long base; int stride;
+    if (axis) {                                      // i = (plane*h + y) * out_len + o
+      o = (int)(i % out_len);
+      base = (i / out_len) * w; stride = 1;
+    } else {                                         // i = (plane*out_len + o) * w + x
+      const int x = (int)(i % w);
+      const long long r = i / w;
+      o = (int)(r % out_len);
+      base = (r / out_len) * (long long)h * w + x; stride = w;
+    }
+    first = bounds[2 * o]; cnt = bounds[2 * o + 1];
+    const int* k = coefs + (size_t)o * ksize;
+    int ss = 1 << 21;
+    for (int t = 0; t < cnt; ++t) ss += (int)src[base + (long long)(first + t) * stride] * k[t];
+    ss >>= 22;                                        // arithmetic shift, then Pillow's clip8 lookup: clamp to [0, 255]
+    dst[i] = (uint8_t)(ss < 0 ? 0 : (ss > 255 ? 255 : ss));
+  }
+}
+
+// out[n][c][hw] = lut[c][img[n][c][hw]]: rescale + normalise of the image processor as a table of the 256 values per channel
+__global__ __launch_bounds__(256) void lut_u8_f32_kernel(const uint8_t* __restrict__ img, const float* __restrict__ lut, float* __restrict__ out,
+                                                          int c, int hw, long long total) {
+  GSL(i, total) {
+    const int ch = (int)((i / hw) % c);
+    out[i] = lut[ch * 256 + img[i]];
+  }
+}
+
 __global__ __launch_bounds__(256) void brightness_kernel(const uint8_t* __restrict__ img, float* __restrict__ rewards, int hw) {
   __shared__ double red[4];
   const uint8_t* p = img + (size_t)blockIdx.x * 3 * hw;
@@ -568,6 +608,24 @@ extern "C" int dts_cosine_rows(const float* a, const float* b, int b_rows, float
   ST;
   hipLaunchKernelGGL(cosine_rows_kernel, dim3(n), dim3(64), 0, st, a, b, b_rows, out, d);
   DTS_CHECK_LAUNCH("dts_cosine_rows");
+  return DTS_OK;
+}
+extern "C" int dts_resample_u8(const uint8_t* src, uint8_t* dst, int planes, int h, int w, int out_len, int axis, const int32_t* bounds,
+                               const int32_t* coefs, int ksize, dts_stream s) {
+  DTS_CHECK_ARG(src && dst && bounds && coefs, "dts_resample_u8: null pointer");
+  DTS_CHECK_ARG(planes > 0 && h > 0 && w > 0 && out_len > 0 && ksize > 0 && ksize <= 4096 && (axis == 0 || axis == 1), "dts_resample_u8: bad shape");
+  ST;
+  const long long total = axis ? (long long)planes * h * out_len : (long long)planes * out_len * w;
+  hipLaunchKernelGGL(resample_u8_kernel, dim3(grid1d(total)), dim3(256), 0, st, src, dst, planes, h, w, out_len, axis, bounds, coefs, ksize);
+  DTS_CHECK_LAUNCH("dts_resample_u8");
+  return DTS_OK;
+}
+extern "C" int dts_lut_u8_f32(const uint8_t* img, const float* lut, float* out, int n, int c, int hw, dts_stream s) {
+  DTS_CHECK_ARG(img && lut && out && n > 0 && c > 0 && hw > 0, "dts_lut_u8_f32: bad args");
+  ST;
+  const long long total = (long long)n * c * hw;
+  hipLaunchKernelGGL(lut_u8_f32_kernel, dim3(grid1d(total)), dim3(256), 0, st, img, lut, out, c, hw, total);
+  DTS_CHECK_LAUNCH("dts_lut_u8_f32");
   return DTS_OK;
 }
 extern "C" int dts_u8_to_unit_f32(const uint8_t* img, float* out, int64_t count, dts_stream s) {

@@ -398,6 +398,24 @@ def u8_to_unit_f32(img_u8):
     return out
 
 
+def resample_u8(img, out_len, axis, bounds, coefs):
+    """One pass of Pillow's 8-bit separable resampling: img uint8 [planes, h, w] -> [planes, h, out_len] (axis 1) or [planes, out_len, w]
+    (axis 0); bounds int32 [out_len, 2], coefs int32 [out_len, ksize] (clip_preprocess.resample_tables)."""
+    planes, h, w = img.shape
+    out = torch.empty((planes, h, out_len) if axis else (planes, out_len, w), dtype=torch.uint8, device=img.device)
+    _call('dts_resample_u8', _ptr(img, 'img', torch.uint8), _ptr(out), planes, h, w, out_len, int(axis), _ptr(bounds, 'bounds', torch.int32),
+          _ptr(coefs, 'coefs', torch.int32), coefs.shape[1])
+    return out
+
+
+def lut_u8_f32(img, lut):
+    """img uint8 [n, c, h, w], lut f32 [c, 256] -> f32 [n, c, h, w]."""
+    n, c, h, w = img.shape
+    out = torch.empty(img.shape, dtype=torch.float32, device=img.device)
+    _call('dts_lut_u8_f32', _ptr(img, 'img', torch.uint8), _ptr(lut, 'lut', torch.float32), _ptr(out), n, c, h * w)
+    return out
+
+
 def cosine_rows(a, b):
     """a [n,d] f32, b [n,d] or [1,d] f32 -> [n] f32: cosine similarity of the L2-normalised rows (CLIP reward tail)."""
     n, d = a.shape

@@ -52,6 +52,8 @@ def _as_u8_batch(images, device):
 
 
 class BrightnessScorer(Scorer):
+    batched = True
+
     @torch.no_grad()
     def __call__(self, images, prompts, timesteps):
         dev = images.device if isinstance(images, torch.Tensor) and images.is_cuda else torch.device('cuda')
@@ -179,8 +181,13 @@ class CLIPScorer(Scorer):
     `image_processor=` (default `CLIPImageProcessor()`: the stock 224 / CLIP-mean-std pipeline, no files needed) and
     `tokenizer=` (default `ByteTokenizer` sized to the model's vocabulary)."""
 
+    batched = True        # one call scores a whole list / batch of images (the SD loop then calls it once per decoded batch)
+
     def __init__(self, model_id='openai/clip-vit-large-patch14', dtype=torch.float32, model=None, image_processor=None,
-                 tokenizer=None, processor=None, device='cuda'):
+                 tokenizer=None, processor=None, device='cuda', device_preprocess=True):
+        """device_preprocess: run the image processor's resize / rescale / normalise on the GPU (clip_preprocess.DevicePreprocessor:
+        Pillow's integer bicubic + the processor's own value table, identical pixel_values) whenever the images are square uint8 GPU
+        tensors and the processor has the stock configuration; False keeps the reference's host path (images.cpu() + PIL) always."""
         super().__init__(dtype)
         self.device = torch.device(device)
         if processor is not None:                                     # a full CLIPProcessor, as the reference holds
@@ -209,18 +216,27 @@ class CLIPScorer(Scorer):
         self.clip = model.to(self.device).eval()
         self.image_processor, self.tokenizer = image_processor, tokenizer
         self._text_cache = {}
+        self.device_preprocessed = 0                                   # images whose pixel_values were built on the GPU
+        self._dev_pre = None
+        if device_preprocess:
+            from .clip_preprocess import DevicePreprocessor
+            self._dev_pre = DevicePreprocessor(image_processor, self.device)
 
     @torch.no_grad()
     def __call__(self, images, prompts, timesteps=None):
         dev = self.device
         # sd/scorers.py:170-173: float images already in [0,1] are not rescaled, everything else (uint8) is
-        do_rescale = not (isinstance(images, torch.Tensor) and images.dtype == torch.float32 and images.max() <= 1.0)
-        if isinstance(images, list):                                   # the SD loop passes [uint8 tensor [1,3,H,W]] (pipeline...:1114)
-            images = [im[0] if (isinstance(im, torch.Tensor) and im.dim() == 4) else im for im in images]
-            images = [im.cpu() if isinstance(im, torch.Tensor) else im for im in images]
-        elif isinstance(images, torch.Tensor):
-            images = images.cpu()
-        pix = self.image_processor(images=images, return_tensors='pt', do_rescale=do_rescale)['pixel_values']
+        if self._dev_pre is not None and self._dev_pre.supports(images):
+            pix = self._dev_pre(images)                                # uint8 GPU images: the processor's arithmetic on the device
+            self.device_preprocessed += pix.shape[0]
+        else:
+            do_rescale = not (isinstance(images, torch.Tensor) and images.dtype == torch.float32 and images.max() <= 1.0)
+            if isinstance(images, list):                               # the SD loop passes [uint8 tensor [1,3,H,W]] (pipeline...:1114)
+                images = [im[0] if (isinstance(im, torch.Tensor) and im.dim() == 4) else im for im in images]
+                images = [im.cpu() if isinstance(im, torch.Tensor) else im for im in images]
+            elif isinstance(images, torch.Tensor):
+                images = images.cpu()
+            pix = self.image_processor(images=images, return_tensors='pt', do_rescale=do_rescale)['pixel_values']
         img_emb = _features(self.clip.get_image_features(pixel_values=pix.to(self.dtype).to(dev))).float().contiguous()
         n = img_emb.shape[0]
         if prompts is None:

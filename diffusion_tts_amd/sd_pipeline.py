@@ -22,6 +22,14 @@ FIRST expanded child; its rollouts only consume RNG.  The draws are reproduced; 
 reference's code sets out to do -- UCB1 selection, one expansion per simulation, a stochastic DDIM rollout to the last
 timestep, decode + score, visit/reward back-propagation, best-mean child.
 
+Multi-GPU (one process per GPU, torch.distributed over RCCL; parallel.CandidateShards): every rank replays the same
+host RNG, so the candidate noises are known everywhere.  eps-greedy / zero-order shard the N candidates of an iteration, beam shards the
+B*N candidates of a timestep; each rank runs the U-Net, the VAE decode and the scorer on its own candidates only and ONE all-gather of
+the rewards per iteration (eps-greedy) / per timestep (beam) follows.  Survivors never travel: the eps-greedy survivor is a host noise
+tensor, and a beam survivor's latent is one fused DDIM step of replicated inputs (the beam, its noise prediction, the candidate noise),
+which every rank computes for all B*N candidates anyway (32 KB each) -- so no broadcast is needed and the collective count is exactly one
+per search decision.  SD MCTS (reference-faithful default) never scores, so there is nothing to shard; `mcts_backprop` runs replicated.
+
 Prompt handling (pipeline...:812-814, 976-992, `encode_prompt` :330-460): with a `text_encoder` / `tokenizer` pair the
 pipeline encodes `prompt` and `negative_prompt` itself exactly as `encode_prompt` does; `prompt_embeds` /
 `negative_prompt_embeds` may be passed instead.  Missing `latents` are drawn like `prepare_latents` (:671-690).
@@ -34,6 +42,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .parallel import CandidateShards
 
 
 class DDIMScheduler:
@@ -99,7 +108,10 @@ class _MCTSNode:
 
 class SDSearchPipeline:
     def __init__(self, unet, vae, scheduler: Optional[DDIMScheduler] = None, device='cuda', mcts_dead_compute=False,
-                 text_encoder=None, tokenizer=None, mcts_backprop=False):
+                 text_encoder=None, tokenizer=None, mcts_backprop=False, shards: Optional[CandidateShards] = None):
+        """shards: candidate sharding over the ranks of the process group (default: CandidateShards(), a world of one outside
+        torch.distributed); pass CandidateShards(enabled=False) to run the whole search on every rank."""
+        self.shards = shards if shards is not None else CandidateShards()
         self.unet, self.vae = unet, vae
         self.scheduler = scheduler or DDIMScheduler()
         self.device = torch.device(device)
@@ -109,6 +121,8 @@ class SDSearchPipeline:
         self.mcts_backprop = mcts_backprop
         self.text_encoder, self.tokenizer = text_encoder, tokenizer
         self.unet_rows = 0
+        self.decoded = 0                              # images through the VAE decoder on THIS rank
+        self.scorer_calls = 0
 
     @torch.no_grad()
     def encode_prompt(self, prompt, negative_prompt=None):
@@ -142,25 +156,52 @@ class SDSearchPipeline:
         self.unet_rows += 2 * n
         return ops.cfg_combine(out[:n].contiguous(), out[n:].contiguous(), guidance)
 
-    def _score(self, score_function, x0, prompt, scores):
-        """decode + quantise the batch once; the scorer keeps the reference's per-image calling convention."""
+    def _score(self, score_function, x0, prompt, scores=None):
+        """decode + quantise the batch once, then score it: ONE scorer call for the whole batch when the scorer says it takes batches
+        (`scorer.batched`: this package's CLIP / brightness scorers), else the reference's per-image calls (pipeline...:1114)."""
         image = self.vae.decode(x0 / self.vae.config.scaling_factor, return_dict=False)[0].float().contiguous()
         u8 = ops.quantize_u8(image, f32_math=True)
-        vals = []
-        for j in range(u8.shape[0]):
-            s = score_function(images=[u8[j:j + 1]], prompts=[prompt], timesteps=None)
-            vals.append(s.item() if torch.is_tensor(s) else float(s))
-        scores += vals
+        n = u8.shape[0]
+        self.decoded += n
+        if n > 1 and getattr(score_function, 'batched', False):
+            s = score_function(images=[u8[j:j + 1] for j in range(n)], prompts=[prompt], timesteps=None)
+            self.scorer_calls += 1
+            vals = [float(v) for v in (s.float().cpu().tolist() if torch.is_tensor(s) else s)]
+        else:
+            vals = []
+            for j in range(n):
+                s = score_function(images=[u8[j:j + 1]], prompts=[prompt], timesteps=None)
+                self.scorer_calls += 1
+                vals.append(s.item() if torch.is_tensor(s) else float(s))
+        if scores is not None:
+            scores += vals
         return vals
 
+    def _gather(self, local_vals, n_total):
+        """rewards of this rank's candidates [lo, hi) -> the rewards of all n_total candidates, identical on every rank (one all-gather)."""
+        if self.shards.solo:
+            return list(local_vals)
+        t = torch.tensor(local_vals, dtype=torch.float64, device=self.device if self.shards.dev_direct else 'cpu')
+        return self.shards.gather_rewards(t, n_total, 1).cpu().tolist()
+
     def _evaluate(self, noise_pred, t, x, cands_dev, eu, ec, g, eta, score_function, prompt, scores):
-        """candidates [N,1,C,H,W] -> (latents_cand [N,C,H,W], rewards): steps 1083-1114 of the reference for all N at once."""
+        """candidates [N,1,C,H,W] -> (latents_cand [N,C,H,W], rewards of all N): steps 1083-1114 of the reference for all N at once.
+        Sharded: the first DDIM step runs for all N on every rank (replicated inputs, 32 KB per candidate: this is what makes every
+        candidate latent available everywhere), the U-Net / decode / score only for this rank's candidates [lo, hi)."""
         a_t, a_p, sig = self.scheduler.coefficients(t, eta)
         prev, _ = ops.ddim_candidates(x.contiguous(), noise_pred.contiguous(), cands_dev.contiguous(), a_t, a_p, sig, want_x0=False)
         lat_c = prev.reshape(prev.shape[0], *x.shape[1:])
-        np2 = self._eps(lat_c, t, eu, ec, g)                                   # same t, not t-1 (:1090)
-        _, x0 = ops.ddim_candidates(lat_c.contiguous(), np2.contiguous(), None, a_t, a_p, sig)
-        return lat_c, self._score(score_function, x0, prompt, scores)
+        n_total = lat_c.shape[0]
+        lo, hi = self.shards.span(n_total)
+        mine = lat_c[lo:hi].contiguous()
+        vals = []
+        if hi > lo:
+            np2 = self._eps(mine, t, eu, ec, g)                                # same t, not t-1 (:1090)
+            _, x0 = ops.ddim_candidates(mine, np2.contiguous(), None, a_t, a_p, sig)
+            vals = self._score(score_function, x0, prompt)
+        allv = self._gather(vals, n_total)
+        scores += allv
+        return lat_c, allv
 
     def _up(self, t, dtype):
         return t.to(self.device, dtype).contiguous()
@@ -238,7 +279,8 @@ class SDSearchPipeline:
         latents = self._up(latents * sch.init_noise_sigma, dtype)
         shape = tuple(latents.shape)
         scores, g = [], float(guidance_scale)
-        self.unet_rows = 0
+        self.unet_rows = self.decoded = self.scorer_calls = 0
+        coll0 = self.shards.collectives
         # randn_like(latents) on the reference's CPU run draws in the LATENTS' dtype (fp16 latents -> fp16 normal sampler, a
         # different stream from f32 draws rounded to fp16); the candidate arithmetic (:1371-1379) runs in that dtype too
         randn = lambda: torch.randn(shape, dtype=dtype)
@@ -246,21 +288,35 @@ class SDSearchPipeline:
 
         if method == 'beam':
             B, N = params['B'], params['N']
+            self.shards.require_candidates(B * N, 'SD beam search')
             best = [copy.deepcopy(latents) for _ in range(B)]
+            a_eta = eta
             for i, t in enumerate(timesteps):
-                scored, vals = [], []
-                for beam in best:
-                    noise_pred = self._eps(beam, t, eu, ec, g)
-                    cands = torch.stack([randn() for _ in range(N)])           # :1080
+                # the B beams' noise predictions in ONE 2B-row U-Net call (the reference makes B calls of 2 rows: rows are independent)
+                noise_preds = self._eps(torch.cat(best), t, eu, ec, g)
+                a_t, a_p, sig = sch.coefficients(t, a_eta)
+                lat_all = []
+                for b_, beam in enumerate(best):
+                    cands = torch.stack([randn() for _ in range(N)])           # :1080, per beam, in the reference's order
                     for _ in range(N):
                         randn()                                                # dropped variance noise of the second step (:1109)
-                    lat_c, v = self._evaluate(noise_pred, t, beam, self._up(cands, dtype), eu, ec, g, eta, score_function, prompt, scores)
-                    scored += [lat_c[j:j + 1] for j in range(N)]
-                    vals += v
+                    prev, _ = ops.ddim_candidates(beam.contiguous(), noise_preds[b_:b_ + 1].contiguous(), self._up(cands, dtype), a_t, a_p, sig,
+                                                  want_x0=False)
+                    lat_all.append(prev.reshape(N, *beam.shape[1:]))
+                lat_all = torch.cat(lat_all)                                   # [B*N, C, H, W], beam-major like the reference's list
+                lo, hi = self.shards.span(B * N)
+                vals = []
+                if hi > lo:
+                    mine = lat_all[lo:hi].contiguous()
+                    np2 = self._eps(mine, t, eu, ec, g)
+                    _, x0 = ops.ddim_candidates(mine, np2.contiguous(), None, a_t, a_p, sig)
+                    vals = self._score(score_function, x0, prompt)
+                vals = self._gather(vals, B * N)                               # ONE all-gather per timestep
+                scores += vals
                 order = sorted(range(len(vals)), key=lambda k: vals[k], reverse=True)      # stable: first wins ties (:1132)
-                best = [scored[k] for k in order[:B]]
+                best = [lat_all[k:k + 1].clone() for k in order[:B]]           # survivors: already on every rank
             max_score, latents = float('-inf'), best[0]
-            finals = self._score(score_function, torch.cat(best), prompt, scores)          # :1157-1170
+            finals = self._score(score_function, torch.cat(best), prompt, scores)          # :1157-1170 (B images: replicated)
             for lat_c, v in zip(best, finals):
                 if v > max_score:
                     max_score, latents = v, lat_c
@@ -292,6 +348,7 @@ class SDSearchPipeline:
                 pivot = randn()                                                # :1366 (host copy; f32)
                 if method in ('eps_greedy', 'zero_order'):
                     N = params['N']
+                    self.shards.require_candidates(N, 'SD eps-greedy / zero-order search')
                     thr = params['eps'] if method == 'eps_greedy' else 0.0
                     for _ in range(params['K']):
                         cands = []
@@ -324,5 +381,6 @@ class SDSearchPipeline:
             import PIL.Image
             arr = ((image / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).float().cpu().numpy() * 255).round().astype('uint8')
             images = [PIL.Image.fromarray(a) for a in arr]
-        out = types.SimpleNamespace(images=images, nsfw_content_detected=None, latents=latents, scores=scores, unet_rows=self.unet_rows)
+        out = types.SimpleNamespace(images=images, nsfw_content_detected=None, latents=latents, scores=scores, unet_rows=self.unet_rows,
+                                    decoded=self.decoded, scorer_calls=self.scorer_calls, collectives=self.shards.collectives - coll0)
         return out, max_score

@@ -30,9 +30,9 @@ typedef void* dts_stream;
 enum dts_dtype { DTS_F32 = 0, DTS_BF16 = 1, DTS_F16 = 2 };
 enum dts_status { DTS_OK = 0, DTS_ERR_ARG = -1, DTS_ERR_LAUNCH = -2, DTS_ERR_UNSUPPORTED = -3 };
 
-#define DTS_ABI_VERSION 106        /* bumped with every change of a signature or of dts_conv_args (101: ev_start/ev_stop; 102: tuning knobs; 103: dts_cosine_rows; 104: dts_nchw_to_nhwc_pad,
+#define DTS_ABI_VERSION 107        /* bumped with every change of a signature or of dts_conv_args (101: ev_start/ev_stop; 102: tuning knobs; 103: dts_cosine_rows; 104: dts_nchw_to_nhwc_pad,
                                      105: dts_conv_args.gn_coef / gn_silu, dts_conv_fuses_gn;
-                                     head dim 512 in dts_attention; 106: dts_conv_kernel, 128-cout ping-pong blocks) */
+                                     head dim 512 in dts_attention; 106: dts_conv_kernel, 128-cout ping-pong blocks; 107: dts_resample_u8, dts_lut_u8_f32) */
 int dts_version(void);            /* == DTS_ABI_VERSION of the build; a binding must refuse any other value */
 const char* dts_last_error(void);
 /* Tuning knobs (measurement aid; a knob only selects between kernels / block orders / ring depths that give correct results -- the
@@ -163,6 +163,15 @@ int dts_quantize_u8(const void* x, int is_f32, uint8_t* out, int64_t count, dts_
 int dts_brightness(const uint8_t* img, float* rewards, int n, int hw, dts_stream s);
 /* CLIP reward tail (sd/scorers.py:182-183,205-211): out[i] = <a_i/||a_i||, b_i/||b_i||>, f32; b has n rows or 1 (one prompt). */
 int dts_cosine_rows(const float* a, const float* b, int b_rows, float* out, int n, int d, dts_stream s);
+/* CLIP image pre-processing on the device (sd/scorers.py:166-180: `self.processor(images=...)` = transformers CLIPImageProcessor = Pillow's
+ * bicubic resize of the uint8 image + rescale + normalise).  dts_resample_u8: ONE pass of Pillow's separable 8-bit resampling (Resample.c):
+ * dst = clip8((2^21 + sum_k src[first + k] * coef[k]) >> 22) along a row (axis 1: [planes][h][w] -> [planes][h][out_len]) or down a column
+ * (axis 0: -> [planes][out_len][w]); bounds [out_len][2] = (first, count), coefs [out_len][ksize] = Pillow's integer coefficients (built by
+ * clip_preprocess.resample_tables).  dts_lut_u8_f32: out[n][c][hw] = lut[c][img]: the processor's rescale + normalise as a 256-entry table
+ * per channel. */
+int dts_resample_u8(const uint8_t* src, uint8_t* dst, int planes, int h, int w, int out_len, int axis, const int32_t* bounds,
+                    const int32_t* coefs, int ksize, dts_stream s);
+int dts_lut_u8_f32(const uint8_t* img, const float* lut, float* out, int n, int c, int hw, dts_stream s);
 /* f32 NCHW = u8 / 255.0f (scorers.py:153) */
 int dts_u8_to_unit_f32(const uint8_t* img, float* out, int64_t count, dts_stream s);
 

@@ -43,6 +43,26 @@ def get_scorer(backend, scorer_name, device, compute_dtype=None):
     raise ValueError(f"Unknown or invalid scorer '{scorer_name}' for backend '{backend}'")
 
 
+def load_sd_vae(model_id, dev):
+    """The SD VAE of the search loop: this build's HIP decoder (vae.VAEDecoder, drop-in for `vae.decode`) read from the safetensors `vae/`
+    directory of the locally cached SD-1.5 snapshot; diffusers' AutoencoderKL only when that directory cannot be located or read."""
+    from diffusion_tts_amd.vae import VAEDecoder
+    path = os.environ.get('DTS_SD_VAE_DIR')
+    if path is None:
+        try:
+            from huggingface_hub import snapshot_download
+            path = os.path.join(snapshot_download(model_id, local_files_only=True, allow_patterns=['vae/*']), 'vae')
+        except Exception:
+            path = None
+    if path is not None and os.path.isdir(path):
+        try:
+            return VAEDecoder.from_pretrained(path, device=dev, dtype=torch.float16)
+        except (FileNotFoundError, ValueError) as e:
+            print(f'[SD] {path}: {e}; falling back to diffusers AutoencoderKL')
+    from diffusers import AutoencoderKL
+    return AutoencoderKL.from_pretrained(model_id, subfolder='vae', torch_dtype=torch.float16, local_files_only=True).to(dev)
+
+
 def main_sd(args):
     """SD backend (reference main.py:111-147).  The search loop, the fused DDIM candidate step and candidate batching are
     this build's (diffusion_tts_amd/sd_pipeline.py); the U-Net / VAE / text encoder are the stock diffusers / transformers
@@ -55,16 +75,23 @@ def main_sd(args):
                            'available in this image.  Drive diffusion_tts_amd.sd_pipeline.SDSearchPipeline(unet, vae) directly '
                            '(tests/test_gpu_sd.py shows the call).') from e
     from diffusion_tts_amd.sd_pipeline import SDSearchPipeline
+    import torch.distributed as dist
     model_id = 'runwayml/stable-diffusion-v1-5'
-    dev = torch.device(args.device)
+    world, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:                                 # one process per GPU: the candidates of every search decision are sharded (sd_pipeline.py)
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    dev = torch.device('cuda', local) if world > 1 else torch.device(args.device)
     unet = UNet2DConditionModel.from_pretrained(model_id, subfolder='unet', torch_dtype=torch.float16, local_files_only=True).to(dev)
-    vae = AutoencoderKL.from_pretrained(model_id, subfolder='vae', torch_dtype=torch.float16, local_files_only=True).to(dev)
+    vae = load_sd_vae(model_id, dev)
     tok = CLIPTokenizer.from_pretrained(model_id, subfolder='tokenizer', local_files_only=True)
     te = CLIPTextModel.from_pretrained(model_id, subfolder='text_encoder', torch_dtype=torch.float16, local_files_only=True).to(dev)
 
     scorer = get_scorer('sd', args.scorer, dev)
     pipe = SDSearchPipeline(unet, vae, device=dev, text_encoder=te, tokenizer=tok)     # encodes the prompt itself (pipeline...:976-992)
     params = {'N': args.N, 'lambda': args.lambda_, 'eps': args.eps, 'K': args.K, 'B': args.B, 'S': args.S}
+    torch.manual_seed(args.seed)                                                       # same host RNG stream on every rank
     best, best_score = None, float('-inf')
     for _ in range(params['N'] if args.method == 'rejection' else 1):          # reference main.py:134
         lat = torch.randn(1, unet.config.in_channels, unet.config.sample_size, unet.config.sample_size)
@@ -74,8 +101,11 @@ def main_sd(args):
         if score > best_score:
             best, best_score = out, score
     outname = args.output or f'sd_{args.method}_{args.scorer}.png'
-    best.images[0].save(outname)
-    print(f'\n[SD] Saved: {outname}\nBest score: {best_score}\n')
+    if int(os.environ.get('RANK', '0')) == 0:
+        best.images[0].save(outname)
+        print(f'\n[SD] Saved: {outname}\nBest score: {best_score}  (VAE: {type(vae).__name__}, reward collectives: {best.collectives})\n')
+    if world > 1:
+        dist.destroy_process_group()
     return best
 
 

@@ -124,3 +124,67 @@ def test_rccl_branch_runs_on_one_gpu_with_a_world_of_one(manifest):
             assert me['collectives'] == 4 * params['K']
         if method == 'REJECTION_SAMPLING':
             assert me['collectives'] == 1 + b
+
+
+# ---- SD backend: beam / eps-greedy / zero-order sharded over 2 ranks (pipeline_stable_diffusion.py:1080-1134, 1366-1433) --------------
+SD_CASES = [('beam', dict(B=2, N=3)), ('eps_greedy', dict(N=5, K=2, eps=0.4, **{'lambda': 0.15})), ('zero_order', dict(N=4, K=2, **{'lambda': 0.15}))]
+
+
+def _run_sd(use_dist):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from sd_standins import TinyUNet, TinyVAE
+    from diffusion_tts_amd.sd_pipeline import SDSearchPipeline
+    from diffusion_tts_amd.scorers import BrightnessScorer
+    torch.manual_seed(0)
+    unet, vae = TinyUNet().cuda().eval(), TinyVAE().cuda().eval()
+    g = torch.Generator().manual_seed(5)
+    pe, ne = torch.randn(1, 6, 8, generator=g), torch.randn(1, 6, 8, generator=g)
+    lat = torch.randn(1, 4, 8, 8, generator=g)
+    out = []
+    for method, params in SD_CASES:
+        pipe = SDSearchPipeline(unet, vae, device='cuda')
+        torch.manual_seed(11)                                   # the search's host RNG stream: the same on every rank
+        o, score = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, latents=lat.clone(), num_inference_steps=3, score_function=BrightnessScorer(),
+                        method=method, params=params, output_type='pt')
+        out.append(dict(scores=np.array(o.scores, dtype=np.float64), image=o.images.float().cpu().numpy(), latents=o.latents.float().cpu().numpy(),
+                        score=float(score), unet_rows=o.unet_rows, decoded=o.decoded, collectives=o.collectives))
+    return out
+
+
+def _worker_sd(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        q.put((rank, _run_sd(True)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_sd_search_equals_single_process():
+    """Two ranks (gloo, sharing the box's GPU): the SD loops shard the candidates of a search decision -- B*N per timestep for beam, N per
+    iteration for eps-greedy / zero-order -- and give the single-process scores, kept beams (final latents) and image, with ONE reward
+    all-gather per decision and no survivor broadcast, while each rank decodes / evaluates only its share."""
+    single = _run_sd(False)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sd, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    steps = 3
+    for ci, (method, params) in enumerate(SD_CASES):
+        ref = single[ci]
+        assert ref['collectives'] == 0
+        for r in (0, 1):
+            me = got[r][ci]
+            assert me['scores'].shape == ref['scores'].shape and np.allclose(me['scores'], ref['scores'], atol=1e-6), (method, r)
+            assert me['score'] == pytest.approx(ref['score'], abs=1e-6)
+            assert np.abs(me['latents'] - ref['latents']).max() < 1e-5 and np.abs(me['image'] - ref['image']).max() < 1e-5, (method, r)
+            assert me['decoded'] < ref['decoded'] and me['unet_rows'] < ref['unet_rows'], (method, r)
+            assert me['collectives'] == (steps if method == 'beam' else steps * params['K']), (method, me['collectives'])

@@ -98,9 +98,21 @@ def test_vae_decoder_from_a_diffusers_directory(tmp_path, vg):
                                                'layers_per_block': 2, 'latent_channels': 4, 'norm_num_groups': 32, 'scaling_factor': 0.18215,
                                                'up_block_types': ['UpDecoderBlock2D'] * 4}))
     a = VAEDecoder.from_pretrained(str(d), device=DEV, dtype=torch.float16)
+    # the CLI (`main.py --backend sd`, reference main.py:111-147) takes this decoder, not diffusers' AutoencoderKL, when the directory exists
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import main as cli
+    os.environ['DTS_SD_VAE_DIR'] = str(d)
+    try:
+        c = cli.load_sd_vae('runwayml/stable-diffusion-v1-5', torch.device(DEV))
+    finally:
+        del os.environ['DTS_SD_VAE_DIR']
+    assert isinstance(c, VAEDecoder)
     b = VAEDecoder({k: v.float() for k, v in full.items() if not k.startswith('encoder.')}, block_out_channels=boc, device=DEV, dtype=torch.float16)
     z = torch.from_numpy(vg['narrow_z']).to(DEV)
     assert torch.equal(a.decode(z, return_dict=False)[0], b.decode(z, return_dict=False)[0])
+    assert torch.equal(c.decode(z, return_dict=False)[0], b.decode(z, return_dict=False)[0])
     assert a.config.block_out_channels == list(boc) and a.config.scaling_factor == 0.18215
     empty = tmp_path / 'empty'
     empty.mkdir()
