@@ -1,5 +1,6 @@
 """Builds libdts_hip.so (gfx950) in-tree with hipcc.  `python -m diffusion_tts_amd.build [--force]`."""
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -54,7 +55,7 @@ def check_m0(obj):
     """conv_igemm.hip writes M0 (the LDS-DMA destination base) in inline asm and declares it clobbered instead of saving and
     restoring it around every load; hipcc warns that clobbering a reserved register 'may lead to undefined behaviour'.  It is
     sound only while NO compiler-generated instruction in those kernels uses M0.  This pins that: in the gfx950 code object every
-    instruction that names m0 must be one of our own `s_mov_b32 m0, s<N>` (the LDS-DMA loads read M0 implicitly).  Returns the
+    instruction that names m0 must be one of our own `s_mov_b32 m0, s<N>` (or vcc_lo / vcc_hi as the scalar source) (the LDS-DMA loads read M0 implicitly).  Returns the
     number of such writes; raises if anything else touches M0."""
     import glob
     import tempfile
@@ -72,7 +73,9 @@ def check_m0(obj):
             raise RuntimeError('no gfx950 code object found in ' + obj)
         dis = subprocess.run([OBJDUMP, '-d', dev[0]], capture_output=True, text=True).stdout
     uses = [ln.split('//')[0].strip() for ln in dis.splitlines() if 'm0' in ln.split('//')[0]]
-    bad = [u for u in uses if not (u.startswith('s_mov_b32 m0, s') and u.count('m0') == 1)]
+    # our statement is `s_mov_b32 m0, <scalar operand>`; under SGPR pressure hipcc hands it vcc_lo / vcc_hi as that operand
+    ours = re.compile(r'^s_mov_b32 m0, (s\d+|vcc_lo|vcc_hi)$')
+    bad = [u for u in uses if not ours.match(u)]
     if bad or not uses:
         raise RuntimeError(f'conv_igemm code object: {len(bad)} instruction(s) other than our `s_mov_b32 m0, sN` use M0 '
                            f'(first: {bad[:3]}); the M0-clobber shortcut in glds16() is no longer safe')

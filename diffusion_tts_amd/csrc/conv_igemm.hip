@@ -99,9 +99,9 @@ template <> struct Vec4<bf16_t> {
   static __device__ __forceinline__ uint2 pack(const float* f) {
     return make_uint2(pack2_bf16(f[0], f[1]), pack2_bf16(f[2], f[3]));
   }
-  static __device__ __forceinline__ void unpack(const uint2& v, float* f) {
-    f[0] = bf16_bits_to_f32(v.x & 0xffffu); f[1] = bf16_bits_to_f32(v.x >> 16);
-    f[2] = bf16_bits_to_f32(v.y & 0xffffu); f[3] = bf16_bits_to_f32(v.y >> 16);
+  static __device__ __forceinline__ void unpack(const uint2& v, float* f) {          // one instruction per element: shift / mask
+    f[0] = __builtin_bit_cast(float, v.x << 16); f[1] = __builtin_bit_cast(float, v.x & 0xffff0000u);
+    f[2] = __builtin_bit_cast(float, v.y << 16); f[3] = __builtin_bit_cast(float, v.y & 0xffff0000u);
   }
   static __device__ __forceinline__ void load(const bf16_t* p, float* f) {
     const uint2 v = *reinterpret_cast<const uint2*>(p);
@@ -244,6 +244,26 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));   // row_mirror
   return v;
 }
+// The same reduction for EIGHT values at once with the DPP operand folded into the add (v_add_f32_dpp): 32 instructions.  Through the
+// builtin above hipcc emits v_mov_b32_dpp + v_pk_add_f32 + the v_movs that pair up the packed operands -- 3.5 instructions per step and
+// value, 680 of the 1410 instructions of a wave's epilogue (the epilogue is vector-issue bound: tools/conv_stamps.py).  Same steps, same
+// order, same sums.  Interleaving the eight chains keeps >= 7 instructions between a write and the DPP read of the same register (the
+// hazard needs 2 wait states, and nothing pads inside an asm statement).
+__device__ __forceinline__ void row16_sum8(float (&a)[4], float (&b)[4]) {
+#define DTS_DPP_STEP(ctrl_)                                                                     \
+  "v_add_f32_dpp %0, %0, %0 " ctrl_ " row_mask:0xf bank_mask:0xf\n\t"                           \
+  "v_add_f32_dpp %1, %1, %1 " ctrl_ " row_mask:0xf bank_mask:0xf\n\t"                           \
+  "v_add_f32_dpp %2, %2, %2 " ctrl_ " row_mask:0xf bank_mask:0xf\n\t"                           \
+  "v_add_f32_dpp %3, %3, %3 " ctrl_ " row_mask:0xf bank_mask:0xf\n\t"                           \
+  "v_add_f32_dpp %4, %4, %4 " ctrl_ " row_mask:0xf bank_mask:0xf\n\t"                           \
+  "v_add_f32_dpp %5, %5, %5 " ctrl_ " row_mask:0xf bank_mask:0xf\n\t"                           \
+  "v_add_f32_dpp %6, %6, %6 " ctrl_ " row_mask:0xf bank_mask:0xf\n\t"                           \
+  "v_add_f32_dpp %7, %7, %7 " ctrl_ " row_mask:0xf bank_mask:0xf\n\t"
+  asm volatile("s_nop 1\n\t"                                   // the operands may have been written by the instruction just before
+               DTS_DPP_STEP("quad_perm:[1,0,3,2]") DTS_DPP_STEP("quad_perm:[2,3,0,1]") DTS_DPP_STEP("row_half_mirror") DTS_DPP_STEP("row_mirror")
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+#undef DTS_DPP_STEP
+}
 
 // ---- epilogue fast path: 16-bit output, whole pixel tile inside the image batch (always, for the U-Net levels at the batch sizes
 // of the search loop).  No per-lane predication, every global/LDS address is one base per nt plus compile-time offsets:
@@ -279,12 +299,8 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
   float4 bv[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) bv[mt] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const bool add_bias = kp.bias != nullptr && !bias_in_acc;
-  if (add_bias) {
-    const float* bp = kp.bias + cm0 + col0;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) bv[mt] = *reinterpret_cast<const float4*>(bp + mt * 16);
-  }
+  // (the bias is already in the accumulators here: the fast path is 16-bit and un-split, exactly the bias_in_acc condition)
+  (void)bias_in_acc; (void)bv;
   const T* np[NT];
   if constexpr (BNC) {
     const int hw = kp.hout * kp.wout;
@@ -324,7 +340,6 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
     for (int nt = 0; nt < NT; ++nt) {
       float v[4];
       v[0] = acc[mt][nt][0]; v[1] = acc[mt][nt][1]; v[2] = acc[mt][nt][2]; v[3] = acc[mt][nt][3];
-      if (add_bias) { v[0] += bv[mt].x; v[1] += bv[mt].y; v[2] += bv[mt].z; v[3] += bv[mt].w; }
       if constexpr (BNC) {
         float f[4];
         Vec4<T>::unpack(nv[nt], f);
@@ -345,14 +360,13 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
         float f[4];
         Vec4<T>::unpack(pk, f);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { ss4[r] += f[r]; sq4[r] += f[r] * f[r]; }
+        for (int r = 0; r < 4; ++r) { ss4[r] += f[r]; sq4[r] = __builtin_fmaf(f[r], f[r], sq4[r]); }
       }
     }
     if constexpr (want_stats) {
       // 16-lane (pixel) reduction on DPP row operations -- quad swaps, half-row mirror, row mirror: four v_add_f32_dpp per
       // value, no LDS crossbar (__shfl_xor is a ds_bpermute here: 192 of them per wave and tile, plus their waits)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { ss4[r] = row16_sum(ss4[r]); sq4[r] = row16_sum(sq4[r]); }
+      row16_sum8(ss4, sq4);
       if (lrow == 0) {
         float4* d = reinterpret_cast<float4*>(sp + mt * 32);
         d[0] = make_float4(ss4[0], sq4[0], ss4[1], sq4[1]);
@@ -1031,6 +1045,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
       //   2: the pieces first, then the fragment reads (shipped)                                        1109
       // DBG 6 / 7 build orders 1 / 2 whatever the default (tools/conv_bench.py conv_variant=61 / 71).
       constexpr int LOAD_ORDER = DBG == 6 ? 1 : (DBG == 7 ? 2 : PP_LOAD_ORDER);
+      constexpr bool GA_LATE = DBG != 9;      // DBG 9 = the former order (all 20 fragment reads in LOAD), kept for the A/B: conv_variant=91
       if constexpr (LOAD_ORDER != 2) {
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
@@ -1081,8 +1096,10 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
       }
 #pragma unroll
       for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq));
+      if constexpr (!GA_LATE) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) ga[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq + 4));
+      }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every fragment is in registers: slots / buffers may be refilled
       DTS_SEG_MARK(1)                                      // section 1: fragment reads issued and returned
@@ -1109,6 +1126,9 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
           for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
+          // GA_LATE: the weight fragments of the second K half are read HERE, one per four MFMAs, instead of in LOAD (6 of its 20 reads): the
+          // A ring is private to the group and its slot is refilled by this wave's own later LOAD, so no other wave depends on when it is read
+          if constexpr (GA_LATE) ga[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq + 4));
           if constexpr (A_IN_LOAD < AJ) {
             if (i == MT / 2 - 1) {
               __builtin_amdgcn_sched_barrier(0);
@@ -1143,11 +1163,13 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
       if constexpr (fuse_gn) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the normalised piece is in LDS
       DTS_SEG_MARK(3)                                      // section 3: the MFMAs (issue; the last ones still drain)
       __builtin_amdgcn_sched_barrier(0);
-      // everything issued before LOAD(t) has landed -- A_g(t+1), the older halo pieces; only LOAD(t)'s own pieces may fly on
-      if (inflight == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if (inflight == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      else if (inflight == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else if (inflight == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      // everything issued before LOAD(t) has landed -- A_g(t+1), the older halo pieces; only LOAD(t)'s own pieces may fly on.  ONE branch:
+      // with weight pieces issued in LOAD(t) the wait leaves AJ loads outstanding -- its AJ weight pieces, or AJ - 1 of them plus the halo
+      // piece, i.e. at most one piece of this segment (the first one issued, a whole segment old) is waited for early -- and the last two
+      // tiles of a block drain everything.  [The exact count as a 5-way if-chain compiled to six scalar branches: ~150 cycles per tile
+      // on the COMPUTE side, which paces the loop since GA_LATE (tools/conv_stamps.py).]
+      (void)inflight;
+      if (DBG != 1 && t + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AJ) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       DTS_SEG_MARK(4)                                      // section 4: counted vmcnt wait
       asm volatile("s_barrier" ::: "memory");
@@ -1540,6 +1562,7 @@ int conv_dispatch(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes,
     if (variant == 71) return DTS_PP(7);
     if (variant == 81) return DTS_PP(8);     // weight pieces split between LOAD and COMPUTE (measured slower)
 #else
+    if (variant == 91) return DTS_PP(9);     // EXPERIMENT: second-half weight fragments read inside COMPUTE
     if (variant > 1) {
       dts_set_error("dts_conv2d: DTS_CONV_VARIANT=%d selects a diagnostic kernel that this library was built without (-DDTS_DIAG_KERNELS)", variant);
       return DTS_ERR_ARG;

@@ -15,7 +15,7 @@ def build():
     objs = []
     for src in ['conv_igemm.hip', 'conv_small.hip', 'groupnorm.hip', 'attention.hip', 'elementwise.hip']:
         o = os.path.join('/tmp', 'stamps_' + src.replace('.hip', '.o'))
-        if src == 'conv_igemm.hip' or not os.path.exists(o):
+        if src == 'conv_igemm.hip' or not os.path.exists(o) or os.path.getmtime(os.path.join(csrc, src)) > os.path.getmtime(o):
             extra = ['-mllvm', '-amdgpu-mfma-vgpr-form=1'] if src == 'attention.hip' else []
             subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-DDTS_STAMPS', '-DDTS_DIAG_KERNELS', *extra, '-c',
                                    os.path.join(csrc, src), '-o', o], stderr=subprocess.DEVNULL)

@@ -2,7 +2,12 @@
 # scratch GPU job of the moment (one gpurun call): edit, run, read gpurun_out/job_*.  Committed form = the last job run.
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
-timeout -k 10 600 python -m pytest tests/test_gpu_vae.py -m gpu -x -q --timeout 500 2>&1 | tail -3 || exit 1
-{ python tools/sd_bench.py --scorer brightness; python tools/sd_bench.py --host-preprocess; python tools/sd_bench.py;
-  DTS_DIST_BACKEND=gloo python tools/sd_bench.py --gpus 2; } 2>&1 | grep -v amdgpu | grep "^SD beam\|Error\|error" > $O/job_sd.txt
-cat $O/job_sd.txt
+timeout -k 10 900 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "conv or statistics or group_norm" 2>&1 | tail -3 || exit 1
+B="--steps 20 --warmup 2 --no-cpu-baseline --no-e2e --no-parity --no-kernel-timing --no-subrecords"
+run() { echo "$1: $(env $2 python bench.py $B $3 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1)"; }
+run "c64 old lib" "DTS_LIB_PATH=$R/diffusion_tts_amd/libdts_hip_old.so" "--candidates 64"
+run "c64 new" "X=1" "--candidates 64"
+run "c64 old lib" "DTS_LIB_PATH=$R/diffusion_tts_amd/libdts_hip_old.so" "--candidates 64"
+run "c64 new" "X=1" "--candidates 64"
+run "c8 old lib" "DTS_LIB_PATH=$R/diffusion_tts_amd/libdts_hip_old.so" "--candidates 8"
+run "c8 new" "X=1" "--candidates 8"
