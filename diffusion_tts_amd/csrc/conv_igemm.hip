@@ -459,7 +459,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
   // stores 16 contiguous bytes and a wave-instruction covers 1 KiB of whole output rows.
   constexpr bool VIA_LDS = sizeof(T) == 2;
   constexpr int ROWP = BM * 2 + 16;                    // LDS row pitch of the staged tile (pixel-major), bytes
-  static_assert(!VIA_LDS || BN * ROWP <= (NTHR == 256 ? 2 * (BM + BN) * 128 : (6 * 96 + 2 * 328) * 128), "staged tile must fit the ring");
+  // the staged tile must fit the smallest ring a caller has: conv_igemm_kernel 2 x (BM + BN) rows, conv_pp_kernel (BN == 256, 512 threads) its own map
+  static_assert(!VIA_LDS || BN * ROWP <= ((NTHR == 512 && BN == 256) ? (6 * 96 + 2 * 328) * 128 : 2 * (BM + BN) * 128), "staged tile must fit the ring");
   const bool want_stats = NT == 4 && kp.stats != nullptr;
   float* sp = want_stats ? kp.stats + ((size_t)tm.strip(wn) * p_cout) * 2 : nullptr;
 #pragma unroll
@@ -542,12 +543,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
 // block per CU (the small per-GPU batches of a sharded search, MCTS groups, the 8x8 level), where a 2-deep ring makes every K step one
 // full L2 round trip (~2.1k cycles against 768 cycles of MFMAs).
 template <typename T, int MT, int NT, int WM, int WN, bool PF, int STAGES = 2>
-__global__ __launch_bounds__(256, (STAGES == 2 ? 2 : 1)) void conv_igemm_kernel(const ConvP kp) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || STAGES == 2 ? 2 : 1)) void conv_igemm_kernel(const ConvP kp) {
   const char* const p_x1 = kp.x1; const char* const p_x2 = kp.x2; const char* const p_w = kp.w;
   const int p_c1 = kp.c1, p_c2 = kp.c2, p_cin = kp.cin, p_hin = kp.hin, p_win = kp.win, p_hout = kp.hout, p_wout = kp.wout;
   const int p_taps = kp.taps, p_up = kp.up, p_P = kp.P, p_n_ct = kp.n_ct, p_n_pt = kp.n_pt;
-  constexpr int NW = WM * WN;              // 4 waves per block, two blocks per CU (8-wave / 3-stage blocks with one block per
-  static_assert(NW == 4, "4 waves");      // CU and persistent blocks were measured slower: profiles/r01_conv_variants.txt)
+  // 4 waves per block and two blocks per CU is the throughput configuration (8-wave blocks with one block per CU measured slower
+  // when the grid fills the chip twice over: profiles/r01_conv_variants.txt).  8 waves (WM x WN = 4 x 2, half the couts per wave) is
+  // for grids of at most one block per CU: a lone 4-wave block has ONE wave per SIMD, which issues its 10 LDS-DMA pieces (~110 cycles
+  // each) and THEN its 48 MFMAs -- 1900 cycles per K step, the matrix pipe idle 60 % of it (tools/conv_stamps.py); with two waves per
+  // SIMD each issues 5 pieces and 24 MFMAs and one wave's issue stalls sit under the other's MFMAs.
+  constexpr int NW = WM * WN;
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
   constexpr int SLAB = 8 * NW;             // rows staged by one wave-instruction round of the whole block
   constexpr int BM = 16 * MT * WM;         // couts per block
@@ -766,7 +772,7 @@ __global__ __launch_bounds__(256, (STAGES == 2 ? 2 : 1)) void conv_igemm_kernel(
   }
 
   DTS_STAMP(2);
-  conv_epilogue<T, MT, NT, BM, BN>(kp, acc, cm0, linear_tile(pn0), (int)blockIdx.y, wm, wn, lrow, lq, smem, bias_in_acc, stage_off, early_u0, early_u1);
+  conv_epilogue<T, MT, NT, BM, BN, 64 * NW>(kp, acc, cm0, linear_tile(pn0), (int)blockIdx.y, wm, wn, lrow, lq, smem, bias_in_acc, stage_off, early_u0, early_u1);
   DTS_STAMP(3);
   DTS_STAMP_RT(5);
 }
@@ -1416,7 +1422,24 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, C
   if (forced_stages >= 2 && forced_stages <= 4) stages = forced_stages;
   if (std::is_same<T, float>::value) stages = 2;            // parity mode: one configuration
   if ((size_t)stages * (BM + BN) * 128 > 160 * 1024) stages = 3;
+  // 8 waves per block (the same tile, half the couts per wave) when the grid leaves one block per CU; DTS_CONV_WAVES = 4 | 8 forces it
+  bool waves8 = sizeof(T) == 2 && MT % 2 == 0 && (long long)nblk * splits <= 256;
+  const int forced_waves = dts_knob_get(DTS_KNOB_CONV_WAVES);
+  if (forced_waves == 4) waves8 = false;
+  if (forced_waves == 8) waves8 = sizeof(T) == 2 && MT % 2 == 0;
   int rc;
+  if constexpr (sizeof(T) == 2 && MT % 2 == 0) {
+    if (waves8) {
+      if (stages >= 3) rc = launch_conv_staged<T, MT / 2, NT, WM * 2, WN, PF, 3>(q, nblk, splits, st, call);
+      else rc = launch_conv_staged<T, MT / 2, NT, WM * 2, WN, PF, 2>(q, nblk, splits, st, call);
+      if (rc != DTS_OK) return rc;
+      if (splits > 1) {
+        if (stats_in_reduce) q.stats = stats_req;
+        return launch_reduce<T>(q, stats_in_reduce, st);
+      }
+      return DTS_OK;
+    }
+  }
   if (stages == 4) rc = launch_conv_staged<T, MT, NT, WM, WN, PF, (sizeof(T) == 2 ? 4 : 2)>(q, nblk, splits, st, call);
   else if (stages == 3) rc = launch_conv_staged<T, MT, NT, WM, WN, PF, (sizeof(T) == 2 ? 3 : 2)>(q, nblk, splits, st, call);
   else rc = launch_conv_staged<T, MT, NT, WM, WN, PF, 2>(q, nblk, splits, st, call);
@@ -1538,7 +1561,7 @@ int conv_pick_pp(bool f32, const ConvP& p) {
   if (p.gn_coef != nullptr) return (mt == 6 && !p.up) ? 6 : 0;   // dts_conv2d has checked dts_conv_fuses_gn
   if (variant >= 1) return mt;                                   // forced (1) or a timing-only diagnostic build (11/21/41/51)
   const long long blocks_pp = (long long)(p.cout / (32 * mt)) * ((p.P + 255) / 256);
-  const bool auto_pp = p.taps == 9 && (p.residual == nullptr || p.cin >= 384);
+  const bool auto_pp = p.taps == 9;     // (round 2 excluded residual layers with cin < 384: since the COMPUTE-side trims of round 3 the ping-pong kernel wins there too, profiles/r03_conv_variants.txt)
   return (auto_pp && blocks_pp >= 64) ? mt : 0;
 }
 
