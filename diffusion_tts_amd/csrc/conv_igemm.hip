@@ -631,18 +631,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || STAGES == 2 ? 2 : 1)
     else { _Pragma("unroll") for (int j = 0; j < RB; ++j) brow[j] += BKE * ES; }                              \
   }
 
-  // 16-bit modes start the accumulators at the bias (its load hides behind the first tile fetch) instead of adding it in the
-  // epilogue, where the load latency (~1.5k cycles by the in-kernel stamps) sits on every block's critical path; f32 (parity)
-  // adds it last like the reference, and split-K adds it once in the reduce pass.
   const bool bias_in_acc = sizeof(T) == 2 && kp.splits == 1 && kp.bias != nullptr;
-  f32x4_t acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias_in_acc) b0 = *reinterpret_cast<const float4*>(kp.bias + cm0 + wm * 16 * MT + i * 16 + (lane >> 4) * 4);
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{b0.x, b0.y, b0.z, b0.w};
-  }
 
   // issue-side K state (tap, cin offset) runs STAGES-1 tiles ahead of the compute side
   int tap = ks_begin / steps_per_tap, ci0 = (ks_begin - tap * steps_per_tap) * BKE;
@@ -681,6 +670,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || STAGES == 2 ? 2 : 1)
   {
     const uint32_t sb_ = wave_rows + A_BYTES;
     _Pragma("unroll") for (int j = 0; j < RB; ++j) glds16(brow[j], sb_ + j * SLAB * 128);
+  }
+  // 16-bit modes start the accumulators at the bias instead of adding it in the epilogue, where the load latency (~1.5k cycles by the
+  // in-kernel stamps) sits on every block's critical path; f32 (parity) adds it last like the reference, and split-K adds it once in the
+  // reduce pass.  The bias is fetched HERE, behind the first tile's LDS-DMA issue: in front of it, its round trip delayed the first
+  // issue by ~1k cycles in every block (the accumulator initialisation waits for it).
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias_in_acc) b0 = *reinterpret_cast<const float4*>(kp.bias + cm0 + wm * 16 * MT + i * 16 + (lane >> 4) * 4);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{b0.x, b0.y, b0.z, b0.w};
   }
   constexpr int LPT = RA + RB;                         // LDS-DMA loads per wave and tile (vmcnt counts them in issue order)
   if constexpr (STAGES > 2) {
@@ -984,14 +985,6 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
   }
 
   const bool bias_in_acc = kp.splits == 1 && kp.bias != nullptr;
-  f32x4_t acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias_in_acc) b0 = *reinterpret_cast<const float4*>(kp.bias + cm0 + wm * GM + i * 16 + lq * 4);
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{b0.x, b0.y, b0.z, b0.w};
-  }
 
   // ---- prologue: A_g(0), A_g(1), the halo of the first chunk (all pieces).  The launcher makes every K split a whole number of
   // chunks (nk % TAPS == 0, ks_begin % TAPS == 0).
@@ -1005,6 +998,15 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
 #pragma unroll
     for (int j = 0; j < NHP; ++j)
       if (w + 8 * j < npieces) bdma16(hvo[j], rs_x, so_, h_dst + j * (64 * 128));
+  }
+  // accumulators start at the bias; fetched behind the prologue's LDS-DMA issue (in front of it the round trip delayed the first issue)
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias_in_acc) b0 = *reinterpret_cast<const float4*>(kp.bias + cm0 + wm * GM + i * 16 + lq * 4);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{b0.x, b0.y, b0.z, b0.w};
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (fuse_gn) {                               // the first chunk's halo: every wave normalises the pieces it staged
@@ -1561,7 +1563,11 @@ int conv_pick_pp(bool f32, const ConvP& p) {
   if (p.gn_coef != nullptr) return (mt == 6 && !p.up) ? 6 : 0;   // dts_conv2d has checked dts_conv_fuses_gn
   if (variant >= 1) return mt;                                   // forced (1) or a timing-only diagnostic build (11/21/41/51)
   const long long blocks_pp = (long long)(p.cout / (32 * mt)) * ((p.P + 255) / 256);
-  const bool auto_pp = p.taps == 9;     // (round 2 excluded residual layers with cin < 384: since the COMPUTE-side trims of round 3 the ping-pong kernel wins there too, profiles/r03_conv_variants.txt)
+  // a short-K layer whose ping-pong grid fills at most half the chip (64x64 level, 192 -> 192, at the 8 rows per forward of a sharded
+  // search: 128 blocks of 27 tiles) is faster on the 8-wave implicit-GEMM kernel, whose 192 x 128 tiles give twice the blocks and need no
+  // K split: 32 vs 41 us (profiles/r03_conv_variants.txt)
+  const bool short_small = blocks_pp <= 128 && p.taps * (p.cin / 64) <= 27;
+  const bool auto_pp = p.taps == 9 && !short_small;     // (round 2 excluded residual layers with cin < 384: since the COMPUTE-side trims of round 3 the ping-pong kernel wins there too, profiles/r03_conv_variants.txt)
   return (auto_pp && blocks_pp >= 64) ? mt : 0;
 }
 
