@@ -1074,7 +1074,12 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
       if (do_piece) gv = *gp;
       int inflight = 0;                                  // pieces issued in this LOAD: they may still be flying when COMPUTE(t) ends
       if constexpr (DBG != 1) {
-        if (t + 2 < nk) { PP_ISSUE_A_PIECES(0, A_IN_LOAD); inflight = AJ; }        // A_g(t+2): the rest follows in COMPUTE(t)
+        if (t + 2 < nk) {                                   // A_g(t+2)
+          PP_ISSUE_A_PIECES(0, A_IN_LOAD); inflight = AJ;
+          // the ring bookkeeping for the next issue belongs HERE, in LOAD: at the end of COMPUTE its scalar instructions sat behind the
+          // last MFMA on the side of the loop that sets the pace (tools/conv_stamps.py: COMPUTE 1040 vs LOAD 950 cycles per tile)
+          if constexpr (A_IN_LOAD == AJ && DBG != 2) PP_ADVANCE_A();
+        }
         if (more) {
           if constexpr (p_taps == 9) {
             if (tap < NHP) {
@@ -1165,7 +1170,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
             }
           }
         }
-        if (a_more) PP_ADVANCE_A();
+        if constexpr (A_IN_LOAD != AJ) { if (a_more) PP_ADVANCE_A(); }
       }
       __builtin_amdgcn_s_setprio(0);
       if constexpr (fuse_gn) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the normalised piece is in LDS
