@@ -1,41 +1,41 @@
 #!/bin/bash
-# copies the summaries of tools/final_run.sh (gpurun_out/final_*) into profiles/ under their round-2 names
+# copies the summaries of tools/final_run.sh (gpurun_out/final_*) into profiles/ under the round's names:  tools/collect_profiles.sh r03
 set -e
 cd "$(dirname "$0")/.."
-O=gpurun_out
-new=$(ls -t $O/final_prof/*/*kernel_stats.csv | head -1)
-cp "$new" profiles/r02_bench_kernel_stats.csv
-cp $O/final_bench.json profiles/r02_bench.json
-cp $O/final_hbm_traffic_pmc.json profiles/r02_hbm_traffic_pmc.json
-cp $O/final_conv_sequence.json profiles/r02_conv_sequence.json
+RD=${1:-r03}; O=gpurun_out
+cp "$(ls -t $O/final_prof/*/*kernel_stats.csv | head -1)" profiles/${RD}_bench_kernel_stats.csv
+cp "$(ls -t $O/final_prof_c8/*/*kernel_stats.csv | head -1)" profiles/${RD}_c8_kernel_stats.csv
+grep "^{" $O/final_bench.json > profiles/${RD}_bench.json
+cp $O/final_hbm_traffic_pmc.json profiles/${RD}_hbm_traffic_pmc.json
+cp $O/final_conv_sequence.json profiles/${RD}_conv_sequence.json
 { echo "# per conv layer shape of one search iteration (bench.py --conv-sequence): PMC HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes) next to the algorithmic bytes"
   echo "# (every input / weight / residual element read once, every output element written once).  x 'launches per step'; time and TFLOP/s from the in-process dispatch events."
-  echo "# Split-K layers (8x8 level, some 16x16) carry their f32 slab write + re-read: x4-6; the 64x64 and 32x32 layers sit at x1.0-1.6."
-  cat $O/final_pmc_per_shape.txt; } > profiles/r02_conv_per_shape_pmc.txt
-grep -v amdgpu.ids $O/final_bench.err > profiles/r02_bench_stderr_conv_table.txt
-for p in rej32:ddpmpp32_rejection cand8:candidates8 mcts:mcts_s256 2rank_gloo:2rank_gloo_one_gpu f16:f16 rccl1:rccl_one_rank; do
-  a=${p%%:*}; b=${p##*:}; grep "^{" $O/final_bench_$a.json > profiles/r02_bench_$b.json
+  cat $O/final_pmc_per_shape.txt; } > profiles/${RD}_conv_per_shape_pmc.txt
+grep -v amdgpu.ids $O/final_bench.err > profiles/${RD}_bench_stderr_conv_table.txt
+for p in mcts:mcts_s256 2rank_gloo:2rank_gloo_one_gpu f16:f16 rccl1:rccl_one_rank; do
+  a=${p%%:*}; b=${p##*:}; grep "^{" $O/final_bench_$a.json > profiles/${RD}_bench_$b.json
 done
-{ echo "# DTS_SHARD_ALWAYS_COLLECT=1 NCCL_DEBUG=VERSION python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-e2e --no-kernel-timing  (one MI355X):"
-  echo "# a ONE-rank RCCL process group (init with device_id) whose reward all-gather, barriers and max-over-ranks all-reduce are all issued on device tensors"
-  grep -v amdgpu $O/final_bench_rccl1.err | tail -8; } > profiles/r02_bench_rccl_one_rank.log
-grep -v amdgpu.ids $O/final_vae.txt > profiles/r02_vae_decode.txt
-grep -v amdgpu.ids $O/final_att.txt > profiles/r02_attention_xcd_n64.txt
-{ echo "# tools/pp_stress.py on an MI355X: conv_pp_kernel forced (DTS_CONV_VARIANT=1) on every production shape class, 12 launches each with L2/MALL evictions and idle"
-  echo "# gaps in between: every launch bit-identical to the first (outputs and strip statistics) and within one output ulp of the f32 parity kernel."
-  grep -v amdgpu $O/final_pp_stress.txt; } > profiles/r02_conv_pp_stress.txt
-{ echo "# tools/sd_bench.py on one MI355X: BASELINE config 4 with this build's parts -- SD beam search B=4, N=16, [N,4,64,64] fp16 latents, candidate-batched U-Net calls"
-  echo "# (stand-in U-Net), fused DDIM candidate step, N-row decodes through the HIP VAE decoder (SD-1.5 width, random init); 4 DDIM steps = 260 candidate decodes."
-  echo "# The CLIP line pays the reference's host-side PIL image processor (transformers CLIPImageProcessor) for every candidate; brightness shows the loop + decoder."
-  grep "^SD beam" $O/final_sd.txt; } > profiles/r02_sd_config4.txt
+for n in 1 2 4 8; do [ -f $O/final_scale_n$n.json ] && grep "^{" $O/final_scale_n$n.json > profiles/${RD}_scale_n$n.json; done
+{ echo "# DTS_SHARD_ALWAYS_COLLECT=1 NCCL_DEBUG=VERSION python bench.py ... (one MI355X): a ONE-rank RCCL process group whose reward all-gather, barriers and"
+  echo "# max-over-ranks all-reduce are all issued on device tensors"
+  grep -v amdgpu $O/final_bench_rccl1.err | tail -8; } > profiles/${RD}_bench_rccl_one_rank.log
+grep -v amdgpu.ids $O/final_vae.txt > profiles/${RD}_vae_decode.txt
+grep -v amdgpu.ids $O/final_att.txt > profiles/${RD}_attention.txt
+{ echo "# tools/sd_bench.py on one MI355X: BASELINE config 4 with this build's parts (see profiles/r03_sd_config4.txt header in git history / DESIGN.md section 5)"
+  grep "^SD beam" $O/final_sd.txt; } > profiles/${RD}_sd_config4_final.txt
+{ echo "# tools/conv_bench.py --n 64 --stats (with residual): 4-wave kernel | ping-pong kernel (shipped) | ping-pong with all 20 fragment reads in LOAD (the round-2 order)"
+  grep -v amdgpu $O/final_conv_variants_n64.txt
+  echo; echo "# tools/conv_bench.py --n 8 --stats: conv_igemm_kernel with 4 waves | with 8 waves (forced on every grid; the launcher picks it for grids <= 256 blocks) | ping-pong forced"
+  grep -v amdgpu $O/final_conv_variants_n8.txt; } > profiles/${RD}_conv_variants.txt
+{ echo "# tools/conv_stamps.py (second library built with -DDTS_STAMPS): in-kernel s_memtime stamps, per block median cycles; N = 64 rows, then 8 rows"
+  grep -v amdgpu $O/final_stamps_n64.txt; echo; grep -v amdgpu $O/final_stamps_n8.txt; } > profiles/${RD}_conv_stamps.txt
 tail -2 $O/final_pytest.log
-python - <<'PY'
-import json
-d=json.loads(open('profiles/r02_bench.json').read().strip().splitlines()[-1])
+python - $RD <<'PY'
+import json, sys
+rd = sys.argv[1]
+d=json.loads(open(f'profiles/{rd}_bench.json').read().strip().splitlines()[-1])
 r=d['roofline']
 print('value',d['value'],'ms',d['ms_per_step'],'dom',r['kernel'],r['achieved'],r['frac'],'all',r['all_conv']['achieved'],r['all_conv']['frac'],'step frac',r['whole_step_frac'])
-print('e2e',d.get('e2e_evals_per_s'),d.get('e2e_seconds_per_image'),'cpu',d['cpu_baseline']['value'])
-p=d['parity']; print({k:p[k] for k in ('f32','f16','bf16')}); print(p['index_agreement']['f16'],p['index_agreement']['bf16'],p['index_agreement']['f32_reward_given_up'])
-for n in ('ddpmpp32_rejection','candidates8','mcts_s256','2rank_gloo_one_gpu','f16','rccl_one_rank'):
-    e=json.loads(open(f'profiles/r02_bench_{n}.json').read().strip().splitlines()[-1]); print(n,e['value'],e['ms_per_step'],e.get('weak_value'),(e.get('roofline') or {}).get('frac'))
+print('e2e',d.get('e2e_evals_per_s'),'cpu',d['cpu_baseline']['value'], 'agreement', d['parity']['index_agreement'])
+for k,v in d.get('sub_records',{}).items(): print(k, v.get('value'), v.get('ms_per_step'), (v.get('roofline') or {}).get('frac'), v.get('cpu_baseline'))
 PY

@@ -37,9 +37,10 @@ def conv_dispatches(directory, counter):
             n = short(r['Kernel_Name'])
             if n.startswith('conv_pp_kernel') or n.startswith('conv_igemm_kernel'):
                 fam = n.split('<')[0]
-                if fam == 'conv_igemm_kernel':
-                    fam += '/3x3' if n.endswith('true>') else '/1x1'
-                elif n.endswith(', 4>'):
+                targs = [t.strip() for t in n[n.index('<') + 1:n.rindex('>')].split(',')]
+                if fam == 'conv_igemm_kernel':           # <T, MT, NT, WM, WN, PF, STAGES>: PF (fragment prefetch) is set for the 3x3 launches
+                    fam += '/3x3' if targs[5] == 'true' else '/1x1'
+                elif targs[4] == '4':                    # conv_pp_kernel<T, TAPS, DBG, GN, MT>: MT = 4 -> 128-cout blocks
                     fam += '/128'
                 out.append((int(r['Dispatch_Id']), fam, float(r['Counter_Value'])))
     out.sort()
@@ -100,10 +101,12 @@ def main():
     fam = {}
     # families as bench.py names them: the ping-pong / halo kernel, and the 4-wave kernel's 3x3 (fragment-prefetch instantiation,
     # last template argument true) and 1x1 launches
-    pick = {'conv_pp_kernel': lambda k: k.startswith('conv_pp_kernel') and not k.endswith(', 4>'),
-            'conv_pp_kernel/128': lambda k: k.startswith('conv_pp_kernel') and k.endswith(', 4>'),
-            'conv_igemm_kernel/3x3': lambda k: k.startswith('conv_igemm_kernel') and k.endswith('true>'),
-            'conv_igemm_kernel/1x1': lambda k: k.startswith('conv_igemm_kernel') and k.endswith('false>'),
+    def targ(k, i):
+        return [t.strip() for t in k[k.index('<') + 1:k.rindex('>')].split(',')][i] if '<' in k else ''
+    pick = {'conv_pp_kernel': lambda k: k.startswith('conv_pp_kernel') and targ(k, 4) != '4',
+            'conv_pp_kernel/128': lambda k: k.startswith('conv_pp_kernel') and targ(k, 4) == '4',
+            'conv_igemm_kernel/3x3': lambda k: k.startswith('conv_igemm_kernel') and targ(k, 5) == 'true',
+            'conv_igemm_kernel/1x1': lambda k: k.startswith('conv_igemm_kernel') and targ(k, 5) == 'false',
             'conv_igemm_kernel': lambda k: k.startswith('conv_igemm_kernel')}
     for famname, f_ in pick.items():
         ks = [v for k, v in kernels.items() if f_(k)]
@@ -111,7 +114,7 @@ def main():
         if nl:
             fam[famname] = {'launches': nl, 'hbm_bytes_per_launch': sum(v['hbm_bytes_per_launch'] * v['launches'] for v in ks) / nl}
     doc = {'kernels_by_family': fam, 'command': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 '
-                      '--no-cpu-baseline --no-kernel-timing --no-e2e',
+                      '--no-cpu-baseline --no-kernel-timing --no-e2e --no-parity --no-subrecords',
            'note': 'FETCH_SIZE/WRITE_SIZE are KiB; gfx950 reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM), hence '
                    'fetch_corrected_x2; Infinity-Cache hits are counted too, so this is an upper bound on HBM reads',
            'kernels': dict(list(kernels.items())[:14])}
