@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
 GFLOP_PER_EVAL = {'adm64': 219.33, 'ddpmpp32': 42.38}             # BASELINE.md section 2 / SURVEY.md 8(d)
 CLS_GFLOP_PER_IMG = 38.16
-TRAFFIC_PROFILE = 'profiles/r02_hbm_traffic_pmc.json'             # written by tools/pmc_traffic.py from the rocprofv3 --pmc passes
+TRAFFIC_PROFILE = 'profiles/r03_hbm_traffic_pmc.json'             # written by tools/pmc_traffic.py from the rocprofv3 --pmc passes
 
 _T0 = time.perf_counter()
 
