@@ -64,7 +64,7 @@ def parse(argv=None):
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-e2e', action='store_true')
     ap.add_argument('--no-weak', action='store_true', help='skip the weak-scaling leg of a multi-rank run')
-    ap.add_argument('--no-subrecords', action='store_true', help='default workload only: skip the sub-records (8 candidates per GPU, 32x32 rejection, MCTS slice, f32 scorer, whole-search index agreement)')
+    ap.add_argument('--no-subrecords', action='store_true', help='default workload only: skip the sub-records (8 candidates per GPU, 32x32 rejection, MCTS slice, f32 scorer, SD beam, whole-search index agreement)')
     ap.add_argument('--mcts-slice', type=int, default=64, help='S of the MCTS sub-record of the default line')
     ap.add_argument('--conv-sequence', default=None, help='write the per-launch conv shape sequence of one step (JSON) for tools/pmc_traffic.py')
     ap.add_argument('--conv-table', action='store_true', help='log the per-shape conv launch table of the instrumented steps')
@@ -589,7 +589,52 @@ def sub_records(a, job, net, scorer, dtype, sd):
     rec = rejection32_record(a32, job, steps=40, warmup=3)
     out['ddpmpp32_rejection'] = {k_: rec[k_] for k_ in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'config', 'roofline', 'cpu_baseline')}
     log(f"sub-record ddpmpp32_rejection: {rec['value']} evals/s, cpu {rec['cpu_baseline']}")
+    # (5) BASELINE configs[3] with this build's parts: SD beam B=4 N=16 over [N,4,64,64] fp16 latents -> [N,3,512,512] decodes
+    try:
+        out['sd_beam_config4'] = sd_beam_record(job)
+        log(f"sub-record sd_beam_config4: {out['sd_beam_config4']['value']} decodes/s")
+    except Exception as e:          # the stand-in U-Net lives with the tests; a tree without them still prints the headline
+        out['sd_beam_config4'] = {'error': f'{type(e).__name__}: {e}'}
     return out
+
+
+def sd_beam_record(job, steps=4, B=4, N=16):
+    """SD beam search at BASELINE configs[3] size through SDSearchPipeline: candidate-batched U-Net calls (a shape-faithful stand-in: the
+    diffusers U-Net is an opaque module on this path and is not available offline), the fused DDIM candidate step, 64-row decodes through
+    the HIP VAE decoder (SD-1.5 width, random init), CLIP scorer (random-init CLIP) with device-side pre-processing, one scorer call per
+    decoded batch.  Unit: candidate decodes per second (the VAE decode, 2.48 TFLOP per candidate, is the part of config 4 this build owns)."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from sd_standins import shape_unet, TinyTextEncoder, TinyTokenizer, tiny_clip
+    from diffusion_tts_amd import init as dinit
+    from diffusion_tts_amd.sd_pipeline import SDSearchPipeline
+    from diffusion_tts_amd.scorers import CLIPScorer, ByteTokenizer
+    from diffusion_tts_amd.vae import VAEDecoder
+    dev = job.dev
+    dec = VAEDecoder(dinit.vae_decoder_state_dict(seed=5), device=dev, dtype=torch.float16)
+    unet, te = shape_unet().half().to(dev), TinyTextEncoder().half().to(dev)
+    pipe = SDSearchPipeline(unet, dec, device=dev, text_encoder=te, tokenizer=TinyTokenizer())
+    scorer = CLIPScorer(model=tiny_clip(0), tokenizer=ByteTokenizer(1000, 998, 999), device=dev)
+    best, nd = None, 0
+    for rep in range(3):
+        torch.manual_seed(7)
+        lat = torch.randn(1, 4, 64, 64).half()
+        d0 = dec.decodes
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        out, _ = pipe(prompt='a photo of a cat', latents=lat, num_inference_steps=steps, score_function=scorer, method='beam',
+                      params={'N': N, 'B': B, 'K': 20, 'lambda': 0.15, 'eps': 0.4, 'S': 8}, output_type='pt')
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        nd = dec.decodes - d0
+    return {'metric': f'candidate VAE decodes/sec, SD beam B={B} N={N}, CLIP scorer', 'value': round(nd / best, 1), 'unit': 'candidate decodes/sec',
+            'seconds_per_search': round(best, 3), 'ddim_steps': steps, 'decodes': nd, 'unet_rows': out.unet_rows, 'scorer_calls': out.scorer_calls,
+            'device_preprocessed_images': scorer.device_preprocessed,
+            'roofline': {'bound': 'mfma', 'achieved': round(nd * 2.48 / best, 1), 'peak': PEAK_TFLOPS['f16'], 'unit': 'TFLOP/s',
+                         'frac': round(nd * 2.48 / best / PEAK_TFLOPS['f16'], 4), 'traffic': None,
+                         'kernel': 'whole search (VAE decoder FLOPs only; stand-in U-Net, CLIP and the loop included in the time)'},
+            'config': {'workload': 'SD-1.5-shaped beam search: [N,4,64,64] fp16 latents, stand-in U-Net, HIP VAE decoder (random init), random-init CLIP scorer'}}
 
 
 def run_eps_greedy(a, job):
