@@ -9,8 +9,10 @@ launches) and replayed with one launch; inputs are copied into the captured inpu
 Not a tracing compiler: nothing is rewritten or fused, the graph is the eager launch sequence.  The first calls of a shape run
 eagerly (they also perform the one-time `hipFuncSetAttribute` calls), the third is captured; a module stops capturing new
 shapes after 8 captures (MCTS rollouts change their batch size all the time).  `DTS_GRAPHS=0` disables it."""
+import gc
 import os
 import warnings
+import weakref
 from collections import OrderedDict
 
 import torch
@@ -23,12 +25,22 @@ SIGHTINGS = 3                       # a shape is captured on its third call
 
 class GraphCache:
     def __init__(self, fn, enabled=None):
-        self.fn = fn
+        # a bound method is held weakly: the owner keeps this cache, and a strong reference back would make every network cyclic
+        # garbage -- its captured graphs and their memory pools would then be released whenever the cycle collector happens to run,
+        # possibly in the middle of ANOTHER graph's stream capture, where releasing a graph aborts the process
+        self._fn = weakref.WeakMethod(fn) if hasattr(fn, '__self__') else (lambda: fn)
         self.enabled = ENABLED if enabled is None else enabled
         self.seen = {}
         self.graphs = OrderedDict()
         self.replays = 0
         self.captures = 0
+
+    @property
+    def fn(self):
+        f = self._fn()
+        if f is None:
+            raise RuntimeError('GraphCache: the module this cache replays has been released')
+        return f
 
     def __call__(self, *inputs):
         """inputs: device tensors (or None); returns a tensor the caller owns."""
@@ -53,15 +65,24 @@ class GraphCache:
 
     def _capture(self, key, inputs):
         static_in = [None if t is None else t.clone() for t in inputs]
+        fn = self.fn
+        # no finaliser may run inside the capture (a collected graph / event / pool of some other module would issue HIP calls that are
+        # illegal while a stream captures): collect what is collectable now, then keep the cycle collector off until the capture ends
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                static_out = self.fn(*static_in)
+                static_out = fn(*static_in)
         except Exception as e:                       # capture refused: stay on the eager launch sequence (same kernels)
             warnings.warn(f'HIP-graph capture failed ({type(e).__name__}: {e}); continuing with eager launches')
             self.enabled = False
             return None
+        finally:
+            if gc_was_on:
+                gc.enable()
         self.captures += 1
         while len(self.graphs) >= MAX_GRAPHS:
             self.graphs.popitem(last=False)

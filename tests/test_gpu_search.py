@@ -261,6 +261,38 @@ def test_network_pkl_path_loads_like_the_state_dict(pkg, golden, manifest, tmp_p
     assert torch.equal(net_a(x, sig, lab), net_b(x, sig, lab))
 
 
+def test_graph_capture_with_garbage_graphs_around(pkg, golden, manifest):
+    """A dropped network whose captured graphs sit in a reference cycle is released by the cycle collector at some later time; inside
+    another network's stream capture that release aborted the process (seen once in a full run of this suite).  graphs.py now holds its
+    owner weakly, collects before a capture and keeps the collector off during it: capture with such garbage around, collector set to
+    run at every allocation."""
+    import gc
+    import weakref
+    cfg, sd = tiny_edm(manifest, 'adm_tiny')
+    x, sig, lab = T(golden['fwd_adm_tiny_hi_x']), T(golden['fwd_adm_tiny_hi_sigma']), T(golden['fwd_labels'])
+    a = pkg['networks'].EDMPrecond(cfg, sd, device=DEV, dtype=torch.float32)
+    ref = a(x, sig, lab).clone()                       # eager (first sighting of the shape)
+    for _ in range(3):
+        a(x, sig, lab)
+    assert a._graphs.captures == 1
+    ra = weakref.ref(a)
+    a.cycle = a                                        # cyclic garbage holding a captured graph and its memory pool
+    del a
+    b = pkg['networks'].EDMPrecond(cfg, sd, device=DEV, dtype=torch.float32)
+    old = gc.get_threshold()
+    gc.set_threshold(1, 1, 1)
+    try:
+        outs = [b(x, sig, lab) for _ in range(4)]      # the third call captures
+    finally:
+        gc.set_threshold(*old)
+    assert b._graphs.captures == 1 and b._graphs.replays >= 1
+    assert all(torch.equal(o, ref) for o in outs)
+    assert ra() is None
+    rb = weakref.ref(b)
+    del b, outs
+    assert rb() is None                                # no cycle of its own: released by reference counting
+
+
 def test_bulk_generation_by_seed(pkg, manifest, tmp_path):
     """bulk.generate_seeds: one search per seed, PNG per seed, and a seed's image is the one generate_image_grid gives for
     the same latents/labels/seed (so it cannot depend on how the seeds are split over ranks)."""
