@@ -335,35 +335,37 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) rv[nt] = *reinterpret_cast<const V4*>(sw + nt * 16 * ROWB + coff[mt]);
     }
-    float ss4[4] = {0.f, 0.f, 0.f, 0.f}, sq4[4] = {0.f, 0.f, 0.f, 0.f};
+    // the element arithmetic runs on PAIRS (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two f32 per lane and issue slot, same IEEE
+    // results): the epilogue is vector-issue bound (two waves per SIMD, ~1.1k vector instructions each per tile)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 ssa = {0.f, 0.f}, ssb = {0.f, 0.f}, sqa = {0.f, 0.f}, sqb = {0.f, 0.f};
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      float v[4];
-      v[0] = acc[mt][nt][0]; v[1] = acc[mt][nt][1]; v[2] = acc[mt][nt][2]; v[3] = acc[mt][nt][3];
+      f32x2 va = {acc[mt][nt][0], acc[mt][nt][1]}, vb = {acc[mt][nt][2], acc[mt][nt][3]};
       if constexpr (BNC) {
         float f[4];
         Vec4<T>::unpack(nv[nt], f);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += f[r];
+        va += f32x2{f[0], f[1]}; vb += f32x2{f[2], f[3]};
       }
       if constexpr (RES) {
         float f[4];
         Vec4<T>::unpack(rv[nt], f);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += f[r];
+        va += f32x2{f[0], f[1]}; vb += f32x2{f[2], f[3]};
       }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] *= osc;
+      va *= osc; vb *= osc;
+      const float v[4] = {va.x, va.y, vb.x, vb.y};
       const V4 pk = Vec4<T>::pack(v);
       *reinterpret_cast<V4*>(sw + nt * 16 * ROWB + coff[mt]) = pk;       // the slot this lane read its residual from
       if constexpr (want_stats) {                      // moments of the values as stored (rounded to T)
         float f[4];
         Vec4<T>::unpack(pk, f);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { ss4[r] += f[r]; sq4[r] = __builtin_fmaf(f[r], f[r], sq4[r]); }
+        const f32x2 fa = {f[0], f[1]}, fb = {f[2], f[3]};
+        ssa += fa; ssb += fb;
+        sqa = __builtin_elementwise_fma(fa, fa, sqa); sqb = __builtin_elementwise_fma(fb, fb, sqb);
       }
     }
     if constexpr (want_stats) {
+      float ss4[4] = {ssa.x, ssa.y, ssb.x, ssb.y}, sq4[4] = {sqa.x, sqa.y, sqb.x, sqb.y};
       // 16-lane (pixel) reduction on DPP row operations -- quad swaps, half-row mirror, row mirror: four v_add_f32_dpp per
       // value, no LDS crossbar (__shfl_xor is a ds_bpermute here: 192 of them per wave and tile, plus their waits)
       row16_sum8(ss4, sq4);
