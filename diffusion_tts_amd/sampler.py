@@ -12,6 +12,7 @@ With torch.distributed initialised (one process per GPU) the N candidates of eac
 across ranks (parallel.CandidateShards): one all-gather of N*B rewards per iteration, identical argmax on every rank.
 """
 import math
+import os
 from dataclasses import dataclass, field
 from enum import Enum, auto
 from typing import Any, Callable, Dict, Optional
@@ -296,6 +297,9 @@ class _Node:
         self.x, self.children, self.reward, self.visit = x, [], 0, visit
 
 
+MCTS_PAD_ROLLOUTS = os.environ.get('DTS_MCTS_PAD', '1') != '0'      # batch the ragged rollouts in multiples of 4 rows (graph replay)
+
+
 def _mcts(L: _Loop, t_steps, x_next, labels, p, pre):
     """edm/main.py:405-713.  Tree statistics, UCB1 selection and the numpy child draw are the reference's; the
     tensor work is re-batched without changing any value: a node's b expansions are one batched step (same x,
@@ -368,7 +372,19 @@ def _mcts(L: _Loop, t_steps, x_next, labels, p, pre):
                         act = [q for q in mine if starts[q][1] <= j]
                         xa = torch.cat([cur[q] for q in act], dim=0)
                         la = None if lb is None else torch.cat([lb[starts[q][2]:starts[q][2] + 1] for q in act], dim=0).contiguous()
+                        # the number of live rollouts changes from step to step (1 .. 16): rounded up to a multiple of 4 with copies of
+                        # row 0, so the denoiser sees four batch shapes and replays their captured HIP graphs instead of launching
+                        # ~500 kernels one by one from the host for every odd size (rows are independent: the live rows' values do
+                        # not depend on the padding; padding rows are not counted as candidate evaluations)
+                        ka = len(act)
+                        kp = ka if (not MCTS_PAD_ROLLOUTS or ka > 16) else -(-ka // 4) * 4
+                        if kp > ka:
+                            xa = torch.cat([xa, xa[:1].expand(kp - ka, *xa.shape[1:])], dim=0)
+                            if la is not None:
+                                la = torch.cat([la, la[:1].expand(kp - ka, la.shape[1])], dim=0).contiguous()
                         xo, _ = L.step(xa, t_steps[j], t_steps[j + 1], j, torch.zeros_like(xa), la)
+                        if kp > ka and hasattr(L.net, 'evals'):
+                            L.net.evals -= (kp - ka) * (2 if j < ns - 1 else 1)
                         for r_, q in enumerate(act):
                             cur[q] = xo[r_:r_ + 1]
                     den = torch.cat([cur[q] for q in mine], dim=0)
