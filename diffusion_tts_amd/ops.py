@@ -5,7 +5,6 @@ no CPU path here (the CPU restatement lives in oracle/ and is test infrastructur
 Activation tensors are NHWC: shape [n, h, w, c], contiguous, dtype float32 / bfloat16 / float16.
 """
 import ctypes as C
-import os
 
 import torch
 
@@ -211,8 +210,6 @@ def gn_apply(x1, coef, *, x2=None, silu=True, pool=False):
     return out
 
 
-GN_SMALL_HW = int(os.environ.get('DTS_GN_SMALL_HW', '0'))
-GN_SMALL_N = int(os.environ.get('DTS_GN_SMALL_N', '16'))
 GN_FUSED_MAX_HW = 64        # 8x8 levels take the single-launch kernel (measured: tools/gn_bench.py; larger levels are bandwidth-bound)
 
 
@@ -246,8 +243,6 @@ def group_norm(x1, groups, eps, gamma, beta, *, x2=None, scale_shift=None, silu=
     c2 = 0 if x2 is None else x2.shape[-1]
     cg = (c1 + c2) // groups
     fused_ok = (not pool) and cg % 2 == 0 and cg <= 64
-    if path is None and fused_ok and h * w <= GN_SMALL_HW and n <= GN_SMALL_N:
-        path = 'fused'           # EXPERIMENT: one launch (statistics recomputed from the tensor) instead of coefficients + apply
     if path in (None, 'strips'):
         coef = _coef_from_strips(x1, x2, groups, eps, gamma, beta, scale_shift)
         if coef is not None:
