@@ -1389,31 +1389,36 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, C
   q.n_pt = (p.P + BN - 1) / BN;
   const int nblk = q.n_ct * q.n_pt;
   const int nk = p.taps * (p.cin / BKE);
-  // split-K when the tile grid cannot fill the chip (256 CUs x resident blocks per CU)
+  // split-K when the tile grid cannot fill the chip.  Two launch forms follow from the grid (see below): at most 256 blocks run as 8 waves
+  // with a 3-deep ring, one block per CU; more run as 4 waves with two co-resident blocks per CU (512 slots).  Estimated microseconds per
+  // form, from tools/conv_stamps.py and the split sweep of tools/conv_bench.py (conv_splits = 1..8 at 4, 8 and 16 rows,
+  // profiles/r03_small_batch_experiments.txt item 9): ~5 us of prologue + epilogue; 0.75 us per K step for the 8-wave form, 1.25 us per step
+  // and round of resident blocks for the 4-wave form; the second pass moves `splits` f32 slabs of P x cout (~3 us + slab bytes at ~4 MB/us),
+  // which for many-pixel layers at a small batch costs more than the shorter K loop saves.
   const int slots = 512;                                     // 256 CUs x 2 resident blocks
   int splits = 1;
   if (ws != nullptr && nblk < (slots * 3) / 4 && nk >= 16) {
-    splits = (slots + nblk - 1) / nblk;
-    if (splits > 8) splits = 8;
-    if (splits > nk / 8) splits = nk / 8;
-    while (splits > 1 && (long long)splits * p.P * p.cout * 4 > ws_bytes) --splits;
-    if (splits < 1) splits = 1;
-    // the second pass moves `splits` f32 slabs of P x cout: for many-pixel layers at a small batch it costs more than the shorter K loop
-    // saves.  Estimated microseconds (tools/conv_stamps.py): ~5.5 us of prologue + epilogue and ~0.95 us per K step per round of
-    // resident blocks; reduce = ~3 us + slab bytes at ~4 MB/us.
-    if (splits > 1) {
-      auto est = [&](int s_) {
-        const int steps = (nk + s_ - 1) / s_;
-        const double rounds = (double)((nblk * s_ + slots - 1) / slots);
-        double t = rounds * (5.5 + steps * 0.95);
-        if (s_ > 1) t += 3.0 + (s_ + 0.5) * (double)p.P * p.cout * 4.0 / 4.0e6;
-        return t;
-      };
-      int best = 1;
-      for (int s_ = 2; s_ <= splits; ++s_)
-        if (est(s_) < est(best)) best = s_;
-      splits = best;
-    }
+    int smax = 8;
+    if (smax > nk / 8) smax = nk / 8;
+    while (smax > 1 && (long long)smax * p.P * p.cout * 4 > ws_bytes) --smax;
+    if (smax < 1) smax = 1;
+    const bool can8 = sizeof(T) == 2 && MT % 2 == 0;
+    auto est = [&](int s_) {
+      const int steps = (nk + s_ - 1) / s_;
+      double t;
+      if (can8 && (long long)nblk * s_ <= 256) t = 5.0 + steps * 0.75;
+      else t = (double)((nblk * s_ + slots - 1) / slots) * (5.5 + steps * 1.25);
+      if (s_ > 1) t += 3.0 + (s_ + 0.5) * (double)p.P * p.cout * 4.0 / 4.0e6;
+      return t;
+    };
+    int best = 1;
+    for (int s_ = 2; s_ <= smax; ++s_)
+      if (est(s_) < est(best)) best = s_;
+    splits = best;
+  }
+  {
+    const int forced = dts_knob_get(DTS_KNOB_CONV_SPLITS);    // DTS_CONV_SPLITS: tuning aid, as in the ping-pong launcher
+    if (forced > 0 && ws != nullptr && nk >= 2 * forced && (long long)forced * p.P * p.cout * 4 <= ws_bytes) splits = forced;
   }
   q.ks_per_split = (nk + splits - 1) / splits;
   splits = (nk + q.ks_per_split - 1) / q.ks_per_split;       // no empty split
