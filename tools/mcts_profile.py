@@ -12,7 +12,6 @@ from diffusion_tts_amd import sampler as sm
 ap = argparse.ArgumentParser()
 ap.add_argument('--S', type=int, default=64)
 a = ap.parse_args()
-args = bench.parse.__wrapped__() if hasattr(bench.parse, '__wrapped__') else None
 sys.argv = [sys.argv[0]]
 ba = bench.parse()
 job = bench.Job(ba)
