@@ -21,10 +21,10 @@ def main():
     ap.add_argument('--n', type=int, default=8)
     ap.add_argument('--iters', type=int, default=7)
     ap.add_argument('--min-us', type=float, default=0.0, help='only print calls whose possible saving per forward is at least this')
+    ap.add_argument('--net', default='adm64', choices=['adm64', 'ddpmpp32'], help='adm64 (+ the classifier) or the DDPM++ CIFAR-32 denoiser of BASELINE configs[0..1]')
     a = ap.parse_args()
     sys.argv = [sys.argv[0]]
     job = bench.Job(bench.parse())
-    net, scorer, _ = bench.build_adm(job, torch.bfloat16, scorer_name='imagenet')
     calls = OrderedDict()
     real = ops.conv2d
 
@@ -34,17 +34,30 @@ def main():
         calls[key] = calls.get(key, 0) + 1
         return real(x1, w, bias, x2=x2, bias_nc=bias_nc, residual=residual, up=up, out_scale=out_scale, out=out, gn_stats=gn_stats, **kw)
 
+    if a.net == 'adm64':
+        net, scorer, _ = bench.build_adm(job, torch.bfloat16, scorer_name='imagenet')
+        mods, res_, nlab = [net, scorer.model], 64, 1000
+    else:
+        from diffusion_tts_amd import init as dinit
+        from diffusion_tts_amd.config import ddpmpp_cifar10
+        from diffusion_tts_amd.networks import EDMPrecond
+        cfg = ddpmpp_cifar10()
+        sd, _ = dinit.refill_degenerate(dinit.edm_state_dict(cfg, 0), 0)
+        net, scorer = EDMPrecond(cfg, sd, device=job.dev, dtype=torch.bfloat16), None
+        mods, res_, nlab = [net], 32, 10
     ops.conv2d = rec
-    g0, g1 = net._graphs.enabled, scorer.model._graphs.enabled
-    net._graphs.enabled = scorer.model._graphs.enabled = False
-    x = torch.randn(a.n, 3, 64, 64, dtype=torch.float64, device=job.dev)
-    lab = torch.eye(1000, device=job.dev)[torch.arange(a.n) % 1000]
+    was = [m._graphs.enabled for m in mods]
+    for m in mods:
+        m._graphs.enabled = False
+    x = torch.randn(a.n, 3, res_, res_, dtype=torch.float64, device=job.dev)
+    lab = torch.eye(nlab, device=job.dev)[torch.arange(a.n) % nlab]
     d = net(x, torch.tensor([1.5], dtype=torch.float64), lab)
-    img = ops.quantize_u8(d.to(torch.float64))
-    scorer(img, lab, torch.zeros(a.n, device=job.dev))
+    if scorer is not None:
+        scorer(ops.quantize_u8(d.to(torch.float64)), lab, torch.zeros(a.n, device=job.dev))
     ops.conv2d = real
-    net._graphs.enabled, scorer.model._graphs.enabled = g0, g1
-    print(f'{len(calls)} distinct conv calls, {sum(calls.values())} launches in one denoiser + one classifier forward at {a.n} rows', flush=True)
+    for m, w_ in zip(mods, was):
+        m._graphs.enabled = w_
+    print(f'{len(calls)} distinct conv calls, {sum(calls.values())} launches in one {a.net} denoiser forward' + (' + one classifier forward' if scorer is not None else '') + f' at {a.n} rows', flush=True)
 
     forms = [('auto', {})]
     for s in (1, 2, 3, 4, 5, 6, 8):
