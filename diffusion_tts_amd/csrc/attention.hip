@@ -44,6 +44,14 @@ __device__ __forceinline__ float vmax2(float a, float b) {
   return r;
 }
 
+__device__ uint4 g_att_zero[64];      // 1 KiB of zeros: LDS-DMA source of key rows past the end of a ragged sequence
+
+// LDS-DMA (global -> LDS, no registers), 16 bytes per active lane; lds_off = wave-uniform LDS byte address of lane 0's slot.  Inline asm:
+// the compiler's s_waitcnt bookkeeping does not see it, completion is awaited with the counted vmcnt below (conv_igemm.hip has the same).
+__device__ __forceinline__ void att_glds16(const char* g, uint32_t lds_off) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_off) : "memory", "m0");
+}
+
 struct AttP {
   const char* qkv; char* out;
   int n, t, heads, d;
@@ -79,9 +87,14 @@ __device__ __forceinline__ void att_block(const AttP& p, int& nh, int& qb) {
 // DB (with PREF): the K/V tiles alternate between two LDS buffers, so a key tile costs ONE block barrier: tile k+1 is written to
 // the other buffer while tile k is still being read (the barrier at the top of the next trip publishes it), and the global
 // loads of tile k+2 go out right behind.  Available where two buffers still leave >= 2 blocks per CU (head dims 64 and 128).
-template <typename T, int D, int QT, int DV = D, bool PREF = true, bool DB = false>
+// DMA (head dim 512 only): K rows (1 KiB = one wave-instruction each) and V-slice rows (512 B: the lower half-wave) go global -> LDS by
+// LDS-DMA instead of through registers (the 256 VGPRs of this instantiation leave no room for a register prefetch, and without one
+// every key tile paid six dependent global-load round trips: the kernel ran 8x below its MFMA time).  K and V have separate buffers
+// and separate phases: K(t+1) flies while the softmax and P.V of tile t run, V(t+1) while Q.K^T of tile t+1 runs; four barriers per tile.
+template <typename T, int D, int QT, int DV = D, bool PREF = true, bool DB = false, bool DMA = false>
 __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
   static_assert(!DB || PREF, "double buffering rides on the register prefetch");
+  static_assert(!DMA || (D == 512 && DV == 256 && QT == 1 && !PREF && !DB), "LDS-DMA staging: the head-dim-512 form only");
   constexpr int ES = 2, ROWB = D * ES + 32;        // LDS row stride of K in bytes
   constexpr int VROWB = DV * ES + 32;              // LDS row stride of the V slice
   constexpr int CH = D / 8;                        // 16-byte chunks per K row
@@ -160,6 +173,25 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
     const int idx = tid + 256 * u, r = idx / CHV, c = idx - r * CHV;                              \
     *reinterpret_cast<uint4*>(sV + (boff_) + r * VROWB + c * 16) = pv[u];                         \
   }
+  // LDS-DMA staging (DMA): wave w stages key rows 16w .. 16w+15 of a tile; vmcnt counts 16 K + 16 V wave-instructions per tile, in issue order
+  const uint32_t lds_k = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)sK;
+  const uint32_t lds_v = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)sV;
+  const char* const zsrc = reinterpret_cast<const char*>(g_att_zero) + lane * 16;
+#define ATT_DMA_K(key0_)                                                                         \
+  _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                \
+    const int r = wid * 16 + i;                                                                   \
+    const char* src = ((key0_) + r < p.t) ? base + (size_t)((key0_) + r) * rowstride + (size_t)C * ES + lane * 16 : zsrc; \
+    att_glds16(src, __builtin_amdgcn_readfirstlane(lds_k + r * ROWB));                            \
+  }
+#define ATT_DMA_V(key0_)                                                                         \
+  if (lane < 32) {                                                                                \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                              \
+      const int r = wid * 16 + i;                                                                 \
+      const char* src = ((key0_) + r < p.t) ? vbase + (size_t)((key0_) + r) * rowstride + lane * 16 : zsrc; \
+      att_glds16(src, __builtin_amdgcn_readfirstlane(lds_v + r * VROWB));                         \
+    }                                                                                             \
+  }
+  if constexpr (DMA) { ATT_DMA_K(0); ATT_DMA_V(0); }
   if constexpr (PREF) { ATT_LOAD_TILE(0); }
   if constexpr (DB) {                                // tile 0 -> buffer 0, tile 1 on its way
     ATT_STAGE_TILE(0);
@@ -168,8 +200,10 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
   for (int kt = 0; kt < ntiles; ++kt) {
     const int key0 = kt * 64;
     const int boff = DB ? (kt & 1) * BUFB : 0;       // this tile's buffer
-    __syncthreads();                                 // DB: tile kt published, tile kt-1 fully consumed; else: previous tile consumed
-    if constexpr (DB) {
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");       // K(kt) has landed; V(kt), issued after it, may still fly
+    __syncthreads();                                 // DB: tile kt published, tile kt-1 fully consumed; else: previous tile consumed; DMA: K(kt) published
+    if constexpr (DMA) {
+    } else if constexpr (DB) {
       if (kt + 1 < ntiles) {
         ATT_STAGE_TILE(BUFB - boff);                 // tile kt+1 into the buffer tile kt-1 occupied
         if (kt + 2 < ntiles) { ATT_LOAD_TILE(key0 + 128); }
@@ -209,7 +243,7 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
         }
       }
     }
-    if constexpr (!DB) {
+    if constexpr (!DB && !DMA) {
       __syncthreads();
       if constexpr (PREF) { if (kt + 1 < ntiles) { ATT_LOAD_TILE(key0 + 64); } }
     }
@@ -226,6 +260,10 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) sacc[qt][j] = AttMma<T>::run(ka, qf[qt][s], sacc[qt][j]);
       }
+    }
+    if constexpr (DMA) {
+      __syncthreads();                               // every wave has read its K fragments: the K buffer is free
+      if (kt + 1 < ntiles) { ATT_DMA_K(key0 + 64); }
     }
     // ---- online softmax; lane holds keys key0 + j*16 + lg*4 + r of query lq.  The running max is kept in the
     // un-scaled domain and the scale (incl. log2 e) is folded into the exponent: exp2(s*sc2 - m*sc2), one FMA per element.
@@ -274,6 +312,11 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
       }
     }
 
+    if constexpr (DMA) {                             // V(kt) has landed (K(kt+1), issued after it, may still fly) and is published
+      if (kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
     // ---- O^T += V^T . P^T ; a V^T fragment feeds every query tile
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -294,6 +337,10 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
         for (int qt = 0; qt < QT; ++qt) o[qt][dt] = AttMma<T>::run(av, pb[qt][kk], o[qt][dt]);
       }
     }
+    if constexpr (DMA) {
+      __syncthreads();                               // every wave has read its V^T fragments: the V buffer is free
+      if (kt + 1 < ntiles) { ATT_DMA_V(key0 + 64); }
+    }
   }
   // ---- store: lane holds channels dt*16 + lg*4 + r of query lq
 #pragma unroll
@@ -311,6 +358,8 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
 }
 #undef ATT_LOAD_TILE
 #undef ATT_STAGE_TILE
+#undef ATT_DMA_K
+#undef ATT_DMA_V
 
 // ------------------------------------------------------------------------------------------------
 // f32 (parity) path: same structure on v_mfma_f32_16x16x4_f32; V needs no transpose (one k per lane group).
@@ -466,7 +515,9 @@ int att16(const AttP& p, hipStream_t st) {
       return db ? launch_att(attention16_kernel<T, 128, 1, 128, true, true>, p, 2 * lds, st) : launch_att(attention16_kernel<T, 128, 1>, p, lds, st);
     case 256: return launch_att(attention16_kernel<T, 256, 1>, p, lds, st);
     case 512:   // two 256-wide value slices per (sample, head, query block); K rows 1056 B + V-slice rows 544 B per key
-      return launch_att(attention16_kernel<T, 512, 1, 256, false>, p, (size_t)64 * (512 * 2 + 32) + (size_t)64 * (256 * 2 + 32), st, 64, 2);
+      if (dts_knob_get(DTS_KNOB_ATT_DB) == 2)     // DTS_ATT_DB=2: the register-staged form (A/B aid)
+        return launch_att(attention16_kernel<T, 512, 1, 256, false>, p, (size_t)64 * (512 * 2 + 32) + (size_t)64 * (256 * 2 + 32), st, 64, 2);
+      return launch_att(attention16_kernel<T, 512, 1, 256, false, false, true>, p, (size_t)64 * (512 * 2 + 32) + (size_t)64 * (256 * 2 + 32), st, 64, 2);
   }
   return DTS_ERR_UNSUPPORTED;
 }
