@@ -46,7 +46,7 @@ enum dts_knob {
   DTS_KNOB_CONV_SPLITS = 3,    // DTS_CONV_SPLITS  forced split-K factor (0/unset: heuristic)
   DTS_KNOB_CONV_VARIANT = 4,   // DTS_CONV_VARIANT kernel structure variant (see conv_igemm.hip)
   DTS_KNOB_GN_FUSE = 5,        // DTS_GN_FUSE      (unused on the C side: networks.py reads the environment variable and passes gn_coef)
-  DTS_KNOB_ATT_DB = 6,         // DTS_ATT_DB       1: double-buffered attention K/V tiles (one barrier per key tile); default single-buffered
+  DTS_KNOB_ATT_DB = 6,         // DTS_ATT_DB       1: double-buffered attention K/V tiles (one barrier per key tile); default single-buffered.  2: head dim 512 with register staging instead of LDS-DMA (A/B aid)
   DTS_KNOB_CONV_STAGES = 7,    // DTS_CONV_STAGES  2|3|4: LDS ring depth of conv_igemm_kernel (default: by grid size)
   DTS_KNOB_CONV_WAVES = 8,     // DTS_CONV_WAVES   4|8: waves per block of conv_igemm_kernel (default: 8 for grids of <= 256 blocks)
   DTS_KNOB_COUNT = 16
