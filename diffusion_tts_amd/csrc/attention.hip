@@ -102,6 +102,8 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
   constexpr int KSTEPS = D / 32;                   // MFMA k-steps for Q.K
   constexpr int DT = DV / 16;                      // output d tiles
   constexpr int NSL = D / DV;                      // value slices
+  constexpr bool WIDE = DMA;                       // fragment reads issued four at a time (see the Q.K^T loop); at D = 256, with the register
+                                                   // prefetch at the 256-VGPR limit, hipcc serialises them again and the DDPM++ step measured 1-3 % slower
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BUFB = 64 * ROWB + 64 * VROWB;      // one K + V tile
   char* sK = smem;
@@ -250,6 +252,25 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
 
     // ---- S^T tiles: 4 x (16 keys x 16 queries) per query tile; a K fragment feeds every query tile
     f32x4_t sacc[QT][4];
+    if constexpr (WIDE) {
+      // long K dimension (16 k-steps): k-step outer, key tile inner -- four independent accumulator chains and four fragment reads in
+      // flight per step.  In the order below (one chain at a time) hipcc, at the register limit of this instantiation, emitted
+      // read -> wait -> MFMA 64 times per key tile: one LDS round trip per MFMA.
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) sacc[qt][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {
+        uint4 ka[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ka[j] = *reinterpret_cast<const uint4*>(sK + boff + (j * 16 + lq) * ROWB + (lg + 4 * s) * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) sacc[qt][j] = AttMma<T>::run(ka[j], qf[qt][s], sacc[qt][j]);
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -260,6 +281,7 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) sacc[qt][j] = AttMma<T>::run(ka, qf[qt][s], sacc[qt][j]);
       }
+    }
     }
     if constexpr (DMA) {
       __syncthreads();                               // every wave has read its K fragments: the K buffer is free
@@ -326,6 +348,24 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) ol[qt] = AttMma<T>::run(ones, pb[qt][kk], ol[qt]);
       const char* vb = va + 16 * VROWB;
+      if constexpr (WIDE) {
+        // four output tiles per round: eight transposed reads in flight, then four independent MFMAs (see the Q.K^T loop above)
+#pragma unroll
+        for (int dt0 = 0; dt0 < DT; dt0 += 4) {
+          uint4 av[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(va + (dt0 + u) * 32));
+            const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vb + (dt0 + u) * 32));
+            const uint2 lo2 = __builtin_bit_cast(uint2, lo), hi2 = __builtin_bit_cast(uint2, hi);
+            av[u] = make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) o[qt][dt0 + u] = AttMma<T>::run(av[u], pb[qt][kk], o[qt][dt0 + u]);
+        }
+      } else {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(va + dt * 32));
@@ -335,6 +375,7 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
         const uint4 av = make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) o[qt][dt] = AttMma<T>::run(av, pb[qt][kk], o[qt][dt]);
+      }
       }
     }
     if constexpr (DMA) {
