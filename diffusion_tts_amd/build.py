@@ -43,43 +43,80 @@ def build(force=False, verbose=False):
             if verbose and warn.strip():
                 print(warn)
     if jobs or force or not os.path.exists(LIB):
-        check_m0(os.path.join(CSRC, 'conv_igemm.o'))
+        for o in M0_OBJECTS:
+            check_m0(os.path.join(CSRC, o))
         run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB, *objs])
     return LIB
 
 
 OBJDUMP = os.environ.get('LLVM_OBJDUMP', '/opt/rocm/lib/llvm/bin/llvm-objdump')
+READELF = os.environ.get('LLVM_READELF', os.path.join(os.path.dirname(OBJDUMP), 'llvm-readelf'))
+# objects whose kernels write M0 in inline asm (LDS-DMA destination) and await the loads with hand-counted s_waitcnt vmcnt(N)
+M0_OBJECTS = ['conv_igemm.o', 'attention.o']
+
+
+def _device_object(obj, tmp):
+    import glob
+    local = os.path.join(tmp, os.path.basename(obj))
+    with open(obj, 'rb') as f, open(local, 'wb') as g:
+        g.write(f.read())
+    subprocess.run([OBJDUMP, '--offloading', local], capture_output=True, text=True, cwd=tmp)
+    dev = glob.glob(local + '.*gfx950*')
+    if not dev:
+        raise RuntimeError('no gfx950 code object found in ' + obj)
+    return dev[0]
 
 
 def check_m0(obj):
-    """conv_igemm.hip writes M0 (the LDS-DMA destination base) in inline asm and declares it clobbered instead of saving and
-    restoring it around every load; hipcc warns that clobbering a reserved register 'may lead to undefined behaviour'.  It is
-    sound only while NO compiler-generated instruction in those kernels uses M0.  This pins that: in the gfx950 code object every
-    instruction that names m0 must be one of our own `s_mov_b32 m0, s<N>` (or vcc_lo / vcc_hi as the scalar source) (the LDS-DMA loads read M0 implicitly).  Returns the
-    number of such writes; raises if anything else touches M0."""
-    import glob
+    """conv_igemm.hip and attention.hip write M0 (the LDS-DMA destination base) in inline asm and declare it clobbered instead of saving
+    and restoring it around every load; hipcc warns that clobbering a reserved register 'may lead to undefined behaviour'.  It is sound
+    only while NO compiler-generated instruction in those kernels uses M0.  This pins that: in the gfx950 code object every instruction
+    that names m0 must be one of our own `s_mov_b32 m0, s<N>` (or vcc_lo / vcc_hi as the scalar source) (the LDS-DMA loads read M0
+    implicitly).  It also pins the second assumption of those kernels: the LDS-DMA loads are awaited with hand-counted `s_waitcnt vmcnt(N)`,
+    and a register spill to scratch would put compiler-generated vmcnt-counted memory operations inside the counted window -- so every
+    kernel of the object that issues LDS-DMA (names m0) with a counted wait (all but the 2-deep-ring conv_igemm_kernel) must have no scratch (.private_segment_fixed_size == 0) and no VGPR spill.
+    Returns the number of M0 writes; raises if anything else touches M0 or such a kernel spills."""
     import tempfile
     if not os.path.exists(OBJDUMP):
-        # the M0-clobber shortcut of glds16()/bdma16() is only sound while this check passes: say loudly that it did not run
-        print(f'WARNING: {OBJDUMP} not found: the M0 safety check of conv_igemm.o was SKIPPED (set LLVM_OBJDUMP)', file=sys.stderr)
+        # the M0-clobber shortcut of glds16()/bdma16()/att_glds16() is only sound while this check passes: say loudly that it did not run
+        print(f'WARNING: {OBJDUMP} not found: the M0 safety check of {os.path.basename(obj)} was SKIPPED (set LLVM_OBJDUMP)', file=sys.stderr)
         return -1
     with tempfile.TemporaryDirectory() as tmp:
-        local = os.path.join(tmp, 'conv_igemm.o')
-        with open(obj, 'rb') as f, open(local, 'wb') as g:
-            g.write(f.read())
-        subprocess.run([OBJDUMP, '--offloading', local], capture_output=True, text=True, cwd=tmp)
-        dev = glob.glob(local + '.*gfx950*')
-        if not dev:
-            raise RuntimeError('no gfx950 code object found in ' + obj)
-        dis = subprocess.run([OBJDUMP, '-d', dev[0]], capture_output=True, text=True).stdout
-    uses = [ln.split('//')[0].strip() for ln in dis.splitlines() if 'm0' in ln.split('//')[0]]
+        dev = _device_object(obj, tmp)
+        dis = subprocess.run([OBJDUMP, '-d', dev], capture_output=True, text=True).stdout
+        notes = subprocess.run([READELF, '--notes', dev], capture_output=True, text=True).stdout if os.path.exists(READELF) else ''
+    name = os.path.basename(obj)
     # our statement is `s_mov_b32 m0, <scalar operand>`; under SGPR pressure hipcc hands it vcc_lo / vcc_hi as that operand
     ours = re.compile(r'^s_mov_b32 m0, (s\d+|vcc_lo|vcc_hi)$')
-    bad = [u for u in uses if not ours.match(u)]
+    uses, bad, dma_kernels, cur = 0, [], set(), None
+    for ln in dis.splitlines():
+        m = re.match(r'^[0-9a-f]+ <([^>]+)>:', ln)
+        if m:
+            cur = m.group(1)
+            continue
+        code = ln.split('//')[0].strip()
+        if 'm0' in code:
+            uses += 1
+            dma_kernels.add(cur)
+            if not ours.match(code):
+                bad.append(code)
     if bad or not uses:
-        raise RuntimeError(f'conv_igemm code object: {len(bad)} instruction(s) other than our `s_mov_b32 m0, sN` use M0 '
-                           f'(first: {bad[:3]}); the M0-clobber shortcut in glds16() is no longer safe')
-    return len(uses)
+        raise RuntimeError(f'{name} code object: {len(bad)} instruction(s) other than our `s_mov_b32 m0, sN` use M0 '
+                           f'(first: {bad[:3]}); the M0-clobber shortcut of the LDS-DMA helpers is no longer safe')
+    # conv_igemm_kernel<..., STAGES = 2> awaits its LDS-DMA with vmcnt(0) only (nothing counted), so a spill there costs time, not
+    # correctness (the f32 192-cout tile, reachable only through DTS_CONV_TILE=192, spills 36 bytes); every other LDS-DMA kernel counts
+    uncounted = re.compile(r'^_ZN\d+_GLOBAL__N_117conv_igemm_kernelI.*Li2EEEvNS_5ConvPE$')
+    if notes:
+        spilled = []
+        for blk in re.split(r'\n\s+- \.agpr_count', notes)[1:]:
+            g = lambda k: re.search(r'\.%s:\s+(\S+)' % k, blk).group(1)
+            if g('name') in dma_kernels and not uncounted.match(g('name')) and (int(g('private_segment_fixed_size')) != 0 or int(g('vgpr_spill_count')) != 0):
+                spilled.append((g('name'), int(g('private_segment_fixed_size')), int(g('vgpr_spill_count'))))
+        if spilled:
+            raise RuntimeError(f'{name}: LDS-DMA kernels with scratch / VGPR spills (their hand-counted vmcnt waits would no longer hold): {spilled[:3]}')
+    else:
+        print(f'WARNING: {READELF} not found: the no-scratch check of the LDS-DMA kernels in {name} was SKIPPED', file=sys.stderr)
+    return uses
 
 
 if __name__ == '__main__':

@@ -110,16 +110,37 @@ class DevicePreprocessor:
             and (not getattr(p, 'do_center_crop', False) or crop == self.size))
         self._tables = {}
         self._lut = None
+        self._probed = False
+
+    def _probe(self):
+        """The attribute test above cannot tell Pillow's integer bicubic resampler from a torchvision-backed 'fast' processor with the same
+        configuration (antialiased float bicubic): run ONE small non-trivial image through the processor itself and through the device path
+        and keep the device path only if the pixel_values are identical."""
+        self._probed = True
+        g = torch.Generator().manual_seed(1234)
+        img = torch.randint(0, 256, (1, 3, 64, 64), dtype=torch.uint8, generator=g)
+        try:
+            want = self.proc(images=[img[0].permute(1, 2, 0).numpy()], return_tensors='pt')['pixel_values'].to(torch.float32)
+            got = self(img.to(self.device)).cpu()
+            ok = tuple(want.shape) == tuple(got.shape) and torch.equal(want, got)
+        except Exception:
+            ok = False
+        if not ok:
+            self.exact = False
 
     def supports(self, images):
         if not self.exact:
             return False
         if isinstance(images, list):
-            return len(images) > 0 and all(isinstance(im, torch.Tensor) and im.is_cuda and im.dtype == torch.uint8 and im.dim() in (3, 4)
-                                           and im.shape[-3] == 3 and im.shape[-1] == im.shape[-2] and (im.dim() == 3 or im.shape[0] == 1)
-                                           and im.shape[-1] == images[0].shape[-1] for im in images)
-        return (isinstance(images, torch.Tensor) and images.is_cuda and images.dtype == torch.uint8 and images.dim() == 4
-                and images.shape[1] == 3 and images.shape[2] == images.shape[3])
+            ok = len(images) > 0 and all(isinstance(im, torch.Tensor) and im.is_cuda and im.dtype == torch.uint8 and im.dim() in (3, 4)
+                                         and im.shape[-3] == 3 and im.shape[-1] == im.shape[-2] and (im.dim() == 3 or im.shape[0] == 1)
+                                         and im.shape[-1] == images[0].shape[-1] for im in images)
+        else:
+            ok = (isinstance(images, torch.Tensor) and images.is_cuda and images.dtype == torch.uint8 and images.dim() == 4
+                  and images.shape[1] == 3 and images.shape[2] == images.shape[3])
+        if ok and not self._probed:
+            self._probe()
+        return ok and self.exact
 
     def __call__(self, images):
         if isinstance(images, list):

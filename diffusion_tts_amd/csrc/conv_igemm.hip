@@ -393,7 +393,8 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
 }
 
 // ---- epilogue of one (cout tile, pixel tile[, K split]): lane holds couts co..co+3 of pixel pp for each (mt, nt)
-template <typename T, int MT, int NT, int BM, int BN, int NTHR = 256>
+// RING: bytes of the caller's (idle) LDS ring, which the staged output tile reuses
+template <typename T, int MT, int NT, int BM, int BN, int NTHR, int RING>
 __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT][NT], int cm0, const TileMap& tm, int split, int wm, int wn,
                                               int lrow, int lq, char* smem, bool bias_in_acc, int stage_off, int early_u0, int early_u1) {
   const int p_P = kp.P, p_cout = kp.cout, p_hout = kp.hout, p_wout = kp.wout;
@@ -461,8 +462,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
   // stores 16 contiguous bytes and a wave-instruction covers 1 KiB of whole output rows.
   constexpr bool VIA_LDS = sizeof(T) == 2;
   constexpr int ROWP = BM * 2 + 16;                    // LDS row pitch of the staged tile (pixel-major), bytes
-  // the staged tile must fit the smallest ring a caller has: conv_igemm_kernel 2 x (BM + BN) rows, conv_pp_kernel (BN == 256, 512 threads) its own map
-  static_assert(!VIA_LDS || BN * ROWP <= ((NTHR == 512 && BN == 256) ? (6 * 96 + 2 * 328) * 128 : 2 * (BM + BN) * 128), "staged tile must fit the ring");
+  static_assert(!VIA_LDS || BN * ROWP <= RING, "staged tile must fit the caller's LDS ring");
   const bool want_stats = NT == 4 && kp.stats != nullptr;
   float* sp = want_stats ? kp.stats + ((size_t)tm.strip(wn) * p_cout) * 2 : nullptr;
 #pragma unroll
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || STAGES == 2 ? 2 : 1)
   }
 
   DTS_STAMP(2);
-  conv_epilogue<T, MT, NT, BM, BN, 64 * NW>(kp, acc, cm0, linear_tile(pn0), (int)blockIdx.y, wm, wn, lrow, lq, smem, bias_in_acc, stage_off, early_u0, early_u1);
+  conv_epilogue<T, MT, NT, BM, BN, 64 * NW, RING_BYTES>(kp, acc, cm0, linear_tile(pn0), (int)blockIdx.y, wm, wn, lrow, lq, smem, bias_in_acc, stage_off, early_u0, early_u1);
   DTS_STAMP(3);
   DTS_STAMP_RT(5);
 }
@@ -1207,7 +1207,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
   __syncthreads();
   DTS_STAMP(2);
 
-  conv_epilogue<T, MT, NT, BM, BN, NTHR>(kp, acc, cm0, tm, (int)blockIdx.y, wm, wn, lrow, lq, smem, bias_in_acc, 0, 0, 0);
+  conv_epilogue<T, MT, NT, BM, BN, NTHR, H_OFF + 2 * H_BUF>(kp, acc, cm0, tm, (int)blockIdx.y, wm, wn, lrow, lq, smem, bias_in_acc, 0, 0, 0);
   DTS_STAMP(3);
   DTS_STAMP_RT(5);
 }
@@ -1418,7 +1418,10 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, C
   }
   {
     const int forced = dts_knob_get(DTS_KNOB_CONV_SPLITS);    // DTS_CONV_SPLITS: tuning aid, as in the ping-pong launcher
-    if (forced > 0 && ws != nullptr && nk >= 2 * forced && (long long)forced * p.P * p.cout * 4 <= ws_bytes) splits = forced;
+    // (the reduce pass is instantiated for 2..8 slabs: a larger forced value is clamped here, as in the ping-pong launcher, instead of
+    // launching the conv kernel and then failing in launch_reduce with the output never produced)
+    const int f8 = forced > 8 ? 8 : forced;
+    if (f8 > 0 && ws != nullptr && nk >= 2 * f8 && (long long)f8 * p.P * p.cout * 4 <= ws_bytes) splits = f8;
   }
   q.ks_per_split = (nk + splits - 1) / splits;
   splits = (nk + q.ks_per_split - 1) / q.ks_per_split;       // no empty split

@@ -8,7 +8,9 @@ launches) and replayed with one launch; inputs are copied into the captured inpu
 
 Not a tracing compiler: nothing is rewritten or fused, the graph is the eager launch sequence.  The first calls of a shape run
 eagerly (they also perform the one-time `hipFuncSetAttribute` calls), the third is captured; a module stops capturing new
-shapes after 8 captures (MCTS rollouts change their batch size all the time).  `DTS_GRAPHS=0` disables it."""
+shapes after 8 captures (MCTS rollouts change their batch size all the time).  `DTS_GRAPHS=0` disables it.
+`DTS_GRAPHS_STRICT=1` (set by bench.py) turns a refused capture into an error instead of a silent return to eager launches: a
+measurement must not report eager-launch numbers under the graph-replay name."""
 import gc
 import os
 import warnings
@@ -77,6 +79,8 @@ class GraphCache:
             with torch.cuda.graph(graph):
                 static_out = fn(*static_in)
         except Exception as e:                       # capture refused: stay on the eager launch sequence (same kernels)
+            if os.environ.get('DTS_GRAPHS_STRICT', '0') == '1':
+                raise RuntimeError(f'HIP-graph capture failed under DTS_GRAPHS_STRICT=1 ({type(e).__name__}: {e})') from e
             warnings.warn(f'HIP-graph capture failed ({type(e).__name__}: {e}); continuing with eager launches')
             self.enabled = False
             return None

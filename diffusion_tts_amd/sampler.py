@@ -96,9 +96,11 @@ class _Loop:
         coef = (t_hat ** 2 - t_cur ** 2).sqrt() * self.S_noise
         return float(t_hat), float(coef)
 
-    def step(self, x_cur, t_cur, t_next, i, eps, labels, nb=None, interleave=False):
-        """edm/main.py:82-96 on the device.  x_cur [xb,...] f64 is broadcast to nb rows; eps [nb,...] f64|f32."""
+    def step(self, x_cur, t_cur, t_next, i, eps, labels, nb=None, interleave=False, live=None):
+        """edm/main.py:82-96 on the device.  x_cur [xb,...] f64 is broadcast to nb rows; eps [nb,...] f64|f32.
+        live: rows that are real candidates (the rest is batch-shape padding): only those count as candidate evaluations."""
         nb = eps.shape[0] if nb is None else nb
+        evals0 = getattr(self.net, 'evals', None)
         t_hat, coef = self.churn(t_cur)
         t_hat_t = torch.tensor([t_hat], dtype=torch.float64)
         x_hat = ops.heun_xhat(x_cur, eps, coef, nb, interleave)
@@ -107,6 +109,8 @@ class _Loop:
         if i < self.num_steps - 1:
             D = self.net(x_next, torch.as_tensor(t_next, dtype=torch.float64).reshape(1), labels)
             ops.heun_correct(x_hat, D, d_cur, t_hat, float(t_next), x_next)
+        if live is not None and live != nb and evals0 is not None:       # padding rows went through the denoiser but are not counted
+            self.net.evals = evals0 + (self.net.evals - evals0) // nb * live
         return x_next, D
 
     def score(self, scorer, x, labels):
@@ -374,17 +378,18 @@ def _mcts(L: _Loop, t_steps, x_next, labels, p, pre):
                         la = None if lb is None else torch.cat([lb[starts[q][2]:starts[q][2] + 1] for q in act], dim=0).contiguous()
                         # the number of live rollouts changes from step to step (1 .. 16): rounded up to a multiple of 4 with copies of
                         # row 0, so the denoiser sees four batch shapes and replays their captured HIP graphs instead of launching
-                        # ~500 kernels one by one from the host for every odd size (rows are independent: the live rows' values do
-                        # not depend on the padding; padding rows are not counted as candidate evaluations)
+                        # ~500 kernels one by one from the host for every odd size.  Rows are independent, so the live rows do not
+                        # depend on the padding VALUES; they can depend on the padded batch SIZE in the last bits, because the conv
+                        # launchers choose the split-K factor / launch form from the row count (another fixed f32 summation order).
+                        # The f32 parity mode therefore runs its rollouts unpadded; padding rows are not counted as evaluations.
                         ka = len(act)
-                        kp = ka if (not MCTS_PAD_ROLLOUTS or ka > 16) else -(-ka // 4) * 4
+                        pad = MCTS_PAD_ROLLOUTS and ka <= 16 and getattr(L.net, 'dtype', None) != torch.float32
+                        kp = -(-ka // 4) * 4 if pad else ka
                         if kp > ka:
                             xa = torch.cat([xa, xa[:1].expand(kp - ka, *xa.shape[1:])], dim=0)
                             if la is not None:
                                 la = torch.cat([la, la[:1].expand(kp - ka, la.shape[1])], dim=0).contiguous()
-                        xo, _ = L.step(xa, t_steps[j], t_steps[j + 1], j, torch.zeros_like(xa), la)
-                        if kp > ka and hasattr(L.net, 'evals'):
-                            L.net.evals -= (kp - ka) * (2 if j < ns - 1 else 1)
+                        xo, _ = L.step(xa, t_steps[j], t_steps[j + 1], j, torch.zeros_like(xa), la, live=ka)
                         for r_, q in enumerate(act):
                             cur[q] = xo[r_:r_ + 1]
                     den = torch.cat([cur[q] for q in mine], dim=0)

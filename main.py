@@ -43,24 +43,23 @@ def get_scorer(backend, scorer_name, device, compute_dtype=None):
     raise ValueError(f"Unknown or invalid scorer '{scorer_name}' for backend '{backend}'")
 
 
-def load_sd_vae(model_id, dev):
-    """The SD VAE of the search loop: this build's HIP decoder (vae.VAEDecoder, drop-in for `vae.decode`) read from the safetensors `vae/`
-    directory of the locally cached SD-1.5 snapshot; diffusers' AutoencoderKL only when that directory cannot be located or read."""
+def load_sd_vae(model_id, dev, kind='hip'):
+    """The SD VAE of the search loop.  kind='hip' (default): this build's HIP decoder (vae.VAEDecoder, drop-in for `vae.decode`) read from
+    the safetensors `vae/` directory of the locally cached SD-1.5 snapshot (or $DTS_SD_VAE_DIR) -- and an error when that directory cannot
+    be found or read: there is no silent fallback.  kind='diffusers' (`--vae diffusers`): the stock AutoencoderKL module, chosen explicitly."""
+    if kind == 'diffusers':
+        from diffusers import AutoencoderKL
+        return AutoencoderKL.from_pretrained(model_id, subfolder='vae', torch_dtype=torch.float16, local_files_only=True).to(dev)
+    if kind != 'hip':
+        raise ValueError(f"--vae must be 'hip' or 'diffusers', got {kind!r}")
     from diffusion_tts_amd.vae import VAEDecoder
     path = os.environ.get('DTS_SD_VAE_DIR')
     if path is None:
-        try:
-            from huggingface_hub import snapshot_download
-            path = os.path.join(snapshot_download(model_id, local_files_only=True, allow_patterns=['vae/*']), 'vae')
-        except Exception:
-            path = None
-    if path is not None and os.path.isdir(path):
-        try:
-            return VAEDecoder.from_pretrained(path, device=dev, dtype=torch.float16)
-        except (FileNotFoundError, ValueError) as e:
-            print(f'[SD] {path}: {e}; falling back to diffusers AutoencoderKL')
-    from diffusers import AutoencoderKL
-    return AutoencoderKL.from_pretrained(model_id, subfolder='vae', torch_dtype=torch.float16, local_files_only=True).to(dev)
+        from huggingface_hub import snapshot_download
+        path = os.path.join(snapshot_download(model_id, local_files_only=True, allow_patterns=['vae/*']), 'vae')
+    if not os.path.isdir(path):
+        raise FileNotFoundError(f'SD VAE directory {path!r} not found (set DTS_SD_VAE_DIR, or pass --vae diffusers for the stock module)')
+    return VAEDecoder.from_pretrained(path, device=dev, dtype=torch.float16)
 
 
 def main_sd(args):
@@ -84,7 +83,7 @@ def main_sd(args):
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     dev = torch.device('cuda', local) if world > 1 else torch.device(args.device)
     unet = UNet2DConditionModel.from_pretrained(model_id, subfolder='unet', torch_dtype=torch.float16, local_files_only=True).to(dev)
-    vae = load_sd_vae(model_id, dev)
+    vae = load_sd_vae(model_id, dev, getattr(args, 'vae', 'hip'))
     tok = CLIPTokenizer.from_pretrained(model_id, subfolder='tokenizer', local_files_only=True)
     te = CLIPTextModel.from_pretrained(model_id, subfolder='text_encoder', torch_dtype=torch.float16, local_files_only=True).to(dev)
 
@@ -129,6 +128,8 @@ def main(argv=None):
     parser.add_argument('--device', type=str, default='cuda', help='Device')
     parser.add_argument('--network', type=str, default='random:adm_imagenet64', help='EDM network spec (see module docstring)')
     parser.add_argument('--dtype', type=str, default='bf16', choices=['bf16', 'f16', 'f32'], help='activation dtype')
+    parser.add_argument('--vae', type=str, default='hip', choices=['hip', 'diffusers'],
+                        help="SD backend: 'hip' = this build's VAE decoder (an error if its safetensors cannot be read), 'diffusers' = the stock module")
     parser.add_argument('--seeds', type=str, default=None, help='bulk mode: seeds, e.g. 0-63 or 1,2,5-10 (one image per seed)')
     parser.add_argument('--outdir', type=str, default='out', help='bulk mode: output directory')
     parser.add_argument('--subdirs', action='store_true', help='bulk mode: one subdirectory per 1000 seeds')
