@@ -38,6 +38,8 @@ def build(force=False, verbose=False):
             raise RuntimeError(f'hipcc failed: {" ".join(cmd)}\n{r.stdout}\n{r.stderr}')
         return r.stderr
 
+    if jobs and os.path.exists(LIB):
+        os.remove(LIB)                  # a failed compile / M0 check must not leave the previous library behind to be measured by mistake
     with ThreadPoolExecutor(max_workers=4) as ex:
         for warn in ex.map(run, jobs):
             if verbose and warn.strip():
