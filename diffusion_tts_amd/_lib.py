@@ -11,7 +11,7 @@ import torch  # noqa: F401  -- must come first: torch ships its own libamdhip64;
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DTS_LIB_PATH') or os.path.join(_HERE, 'libdts_hip.so')     # override: A/B kernel tuning only
 
-DTS_F32, DTS_BF16, DTS_F16 = 0, 1, 2
+DTS_F32, DTS_BF16, DTS_F16, DTS_F16X3 = 0, 1, 2, 3
 
 _p, _i, _f, _d, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int64
 
@@ -22,7 +22,7 @@ class ConvArgs(C.Structure):
                 ('n', C.c_int32), ('hin', C.c_int32), ('win', C.c_int32), ('cout', C.c_int32),
                 ('ksize', C.c_int32), ('up', C.c_int32), ('out_scale', C.c_float), ('dtype', C.c_int32),
                 ('workspace', _p), ('workspace_bytes', C.c_int64), ('stats_out', _p), ('stats_written', C.c_int32),
-                ('ev_start', _p), ('ev_stop', _p), ('gn_coef', _p), ('gn_silu', C.c_int32)]
+                ('ev_start', _p), ('ev_stop', _p), ('gn_coef', _p), ('gn_silu', C.c_int32), ('acc_scale', C.c_float)]
 
 
 # name -> argtypes (every function returns int status except the three noted below)
@@ -44,6 +44,7 @@ SIGNATURES = {
     'dts_pos_embedding': [_p, _p, _p, _i, _i, _i, _p],
     'dts_edm_precond_in': [_p, _p, _i, _f, _p, _p, _i, _i, _p],
     'dts_edm_precond_out': [_p, _p, _p, _p, _i, _i, _p],
+    'dts_split3_f16': [_p, _i, _p, _i, _p, _i64, _p],
     'dts_cast_from_f32': [_p, _p, _i, _i64, _p],
     'dts_cast_to_f32': [_p, _i, _p, _i64, _p],
     'dts_heun_xhat': [_p, _i, _i, _p, _i, _d, _p, _i, _i, _p],
@@ -65,7 +66,7 @@ SIGNATURES = {
 OTHER = {'dts_version': ([], _i), 'dts_conv_fuses_gn': ([C.POINTER(ConvArgs)], _i), 'dts_conv_kernel': ([C.POINTER(ConvArgs)], _i), 'dts_set_tuning': ([_i, _i], _i), 'dts_get_tuning': ([_i], _i), 'dts_last_error': ([], C.c_char_p), 'dts_gn_ws_floats': ([_i, _i], _i64)}
 
 _lib = None
-ABI_VERSION = 107              # include/dts.h DTS_ABI_VERSION this binding was written against (ConvArgs = 176 bytes)
+ABI_VERSION = 108              # include/dts.h DTS_ABI_VERSION this binding was written against (ConvArgs = 176 bytes)
 
 
 def load():

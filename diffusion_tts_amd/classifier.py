@@ -34,6 +34,7 @@ class EncoderUNetModel:
         if not torch.cuda.is_available():
             raise RuntimeError('EncoderUNetModel (HIP) needs a GPU: there is no CPU fallback in this package')
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
+        self.act_dtype = ops.act_dtype(dtype)            # float32 activations in the split-precision mode (ops.F16X3)
         from .graphs import GraphCache
         self._graphs = GraphCache(self._device_forward)
         f = lambda t: t.detach().to(self.device, torch.float32).contiguous()
@@ -113,13 +114,13 @@ class EncoderUNetModel:
         emb = ops.pos_embedding(t, self.freqs)                                   # nn_utils.py:103-121
         emb = ops.linear(emb, self.te0_w, self.te0_b, act_out=True)
         emb = ops.linear(emb, self.te2_w, self.te2_b, act_out=True)              # SiLU of emb_layers[0], shared by all blocks
-        e = ops.cast_from_f32(emb, self.dtype)
+        e = ops.cast_from_f32(emb, self.act_dtype)
         emb_all = ops.conv2d(e.view(1, n, 1, -1), self.emb_w, self.emb_b).view(n, self.emb_total)
         h = None
         for L in self.layers:
             if L.kind == 'conv_in':
                 P = self.params[L.prefix]
-                h = ops.conv_in3(x.contiguous(), P.w, P.b, L.cout, self.dtype)
+                h = ops.conv_in3(x.contiguous(), P.w, P.b, L.cout, self.act_dtype)
             elif L.kind == 'res':
                 h = self._res(L, h, emb_all)
             else:

@@ -54,6 +54,7 @@ struct ConvP {
   float* partial;  // [splits][P][cout] f32 when splits > 1
   float* stats;    // optional [ceil(P/64)][cout][2]: per 64-pixel strip (sum, sumsq) of the stored outputs (GroupNorm input)
   float out_scale;
+  float acc_scale;         // the accumulators are scaled by this before anything is added (split-precision mode: the packed weights carry 2^k)
   int w_shift, hw_shift;   // log2(wout), log2(hout*wout) when both are powers of two, else -1 (pixel coordinates by division)
   const float* gn_coef;    // optional [n][cin][2] (a, b): GroupNorm of the INPUT applied on the staged halo tile (conv_pp_kernel only)
   int gn_silu;
@@ -174,8 +175,8 @@ __device__ unsigned long long g_seg[4096 * 2 * 8];
 #define DTS_SEG_STORE
 #endif
 
-__device__ uint4 g_zero16[512];    // 8 KiB of zeros: source of padded (out-of-image) rows; a row pointer into it is advanced
-                                   // along K like a real one (cin * element size <= 6 KiB), so no per-step select is needed
+__device__ uint4 g_zero16[1024];   // 16 KiB of zeros: source of padded (out-of-image) rows; a row pointer into it is advanced
+                                   // along K like a real one (cin * element size <= 15 KiB: 3 x 1536 channels of the split-precision mode included), so no per-step select is needed
 
 // LDS-DMA through inline asm: hipcc does not count an asm memory op in its s_waitcnt bookkeeping, so it does not
 // drain the in-flight tile in front of the (non-aliasing) ds_reads of the other buffer, as it does for the builtin.
@@ -440,22 +441,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
     ppv[nt] = pp < p_P ? pp : -1;
     nsv[nt] = pp < p_P ? pp / hw : 0;
   }
-  // residual vectors: all MT*NT reads in flight before the first store (a memory round trip per slice otherwise);
-  // the rarer per-sample bias (SongUNet's conv0) is fetched per slice to keep the register budget under 256.
-  V4 rv[MT][NT], nv[NT];
+  // residual vectors: all reads of a slice group in flight before its first store (a memory round trip per slice otherwise); the group
+  // is all MT slices, except for f32 outputs of the wide tiles (MT > 4: 96 residual registers beside 96 accumulators do not fit), which
+  // go two slices at a time; the rarer per-sample bias (SongUNet's conv0) is fetched per slice to keep the register budget under 256.
+  constexpr int RG = (sizeof(T) == 4 && MT > 4) ? 2 : MT;
+  static_assert(MT % RG == 0, "residual slice groups");
+  V4 rv[RG][NT], nv[NT];
   float4 bv[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
     bv[mt] = (kp.bias && !bias_in_acc) ? *reinterpret_cast<const float4*>(kp.bias + cm0 + wm * 16 * MT + mt * 16 + lq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-  if (res) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int co_ = cm0 + wm * 16 * MT + mt * 16 + lq * 4;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-        if (ppv[nt] >= 0) rv[mt][nt] = *reinterpret_cast<const V4*>(res + (size_t)ppv[nt] * p_cout + co_);
-    }
-  }
+  const float asc = kp.acc_scale;
   // 16-bit outputs leave through the (now idle) LDS tile ring: the accumulator layout gives each lane 4 couts of one pixel,
   // i.e. 8-byte stores scattered over 16 pixel rows per instruction, and a timing-only build without the epilogue showed
   // those stores costing a quarter of the whole conv time (2x on the 1x1 layers).  Transposed through LDS, every lane
@@ -469,6 +465,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
   for (int mt = 0; mt < MT; ++mt) {
     const int co = cm0 + wm * 16 * MT + mt * 16 + lq * 4;
     const float4 bcur = bv[mt];
+    if (res && mt % RG == 0) {
+#pragma unroll
+      for (int m2 = 0; m2 < RG; ++m2) {
+        const int co_ = cm0 + wm * 16 * MT + (mt + m2) * 16 + lq * 4;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          if (ppv[nt] >= 0) rv[m2][nt] = *reinterpret_cast<const V4*>(res + (size_t)ppv[nt] * p_cout + co_);
+      }
+    }
     if (bnc) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
@@ -479,8 +484,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
     for (int nt = 0; nt < NT; ++nt) {
       if (ppv[nt] < 0) continue;
       float v[4];
-      v[0] = acc[mt][nt][0] + bcur.x; v[1] = acc[mt][nt][1] + bcur.y;
-      v[2] = acc[mt][nt][2] + bcur.z; v[3] = acc[mt][nt][3] + bcur.w;
+      // (acc_scale is 1 outside the split-precision mode: x * 1 + b rounds once, like x + b)
+      v[0] = acc[mt][nt][0] * asc + bcur.x; v[1] = acc[mt][nt][1] * asc + bcur.y;
+      v[2] = acc[mt][nt][2] * asc + bcur.z; v[3] = acc[mt][nt][3] * asc + bcur.w;
       if (bnc) {
         float f[4];
         Vec4<T>::unpack(nv[nt], f);
@@ -489,7 +495,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
       }
       if (res) {
         float f[4];
-        Vec4<T>::unpack(rv[mt][nt], f);
+        Vec4<T>::unpack(rv[mt % RG][nt], f);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += f[r];
       }
@@ -544,7 +550,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
 // waits: the throughput configuration).  3 / 4 = two / three tiles in flight behind a COUNTED vmcnt: for launches whose grid leaves one
 // block per CU (the small per-GPU batches of a sharded search, MCTS groups, the 8x8 level), where a 2-deep ring makes every K step one
 // full L2 round trip (~2.1k cycles against 768 cycles of MFMAs).
-template <typename T, int MT, int NT, int WM, int WN, bool PF, int STAGES = 2>
+// OT: element type of the epilogue's operands and of the output (bias_nc, residual, out).  OT = T everywhere except the split-precision
+// mode (T = f16 operand planes [hi | lo | hi] against weights [hi | hi | lo], OT = float: dts.h DTS_F16X3), whose epilogue is the f32 one.
+template <typename T, int MT, int NT, int WM, int WN, bool PF, int STAGES = 2, typename OT = T>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || STAGES == 2 ? 2 : 1)) void conv_igemm_kernel(const ConvP kp) {
   const char* const p_x1 = kp.x1; const char* const p_x2 = kp.x2; const char* const p_w = kp.w;
   const int p_c1 = kp.c1, p_c2 = kp.c2, p_cin = kp.cin, p_hin = kp.hin, p_win = kp.win, p_hout = kp.hout, p_wout = kp.wout;
@@ -633,7 +641,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || STAGES == 2 ? 2 : 1)
     else { _Pragma("unroll") for (int j = 0; j < RB; ++j) brow[j] += BKE * ES; }                              \
   }
 
-  const bool bias_in_acc = sizeof(T) == 2 && kp.splits == 1 && kp.bias != nullptr;
+  const bool bias_in_acc = sizeof(OT) == 2 && kp.splits == 1 && kp.bias != nullptr;
 
   // issue-side K state (tap, cin offset) runs STAGES-1 tiles ahead of the compute side
   int tap = ks_begin / steps_per_tap, ci0 = (ks_begin - tap * steps_per_tap) * BKE;
@@ -705,7 +713,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || STAGES == 2 ? 2 : 1)
   // early residual fetch (whole 16-bit tiles only: the ones that take conv_epilogue_fast)
   constexpr int RING_BYTES = STAGES * STAGE_BYTES, STAGED_BYTES = BN * BM * 2, PIECE = 64 * NW * 16, PIECES = STAGED_BYTES / PIECE;
   static_assert(STAGED_BYTES % PIECE == 0 && STAGED_BYTES <= RING_BYTES, "staged tile pieces");
-  const bool res_early = sizeof(T) == 2 && kp.residual != nullptr && kp.splits == 1 && pn0 + BN <= p_P;
+  const bool res_early = sizeof(OT) == 2 && kp.residual != nullptr && kp.splits == 1 && pn0 + BN <= p_P;
   int stage_off = 0, early_u0 = 0, early_u1 = 0;
   int buf = 0;
   for (int ks = ks_begin; ks < ks_end; ++ks) {
@@ -775,7 +783,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || STAGES == 2 ? 2 : 1)
   }
 
   DTS_STAMP(2);
-  conv_epilogue<T, MT, NT, BM, BN, 64 * NW, RING_BYTES>(kp, acc, cm0, linear_tile(pn0), (int)blockIdx.y, wm, wn, lrow, lq, smem, bias_in_acc, stage_off, early_u0, early_u1);
+  conv_epilogue<OT, MT, NT, BM, BN, 64 * NW, RING_BYTES>(kp, acc, cm0, linear_tile(pn0), (int)blockIdx.y, wm, wn, lrow, lq, smem, bias_in_acc, stage_off, early_u0, early_u1);
   DTS_STAMP(3);
   DTS_STAMP_RT(5);
 }
@@ -841,7 +849,7 @@ __device__ __forceinline__ uint4 gn_act8(const uint4 v, const float (&ca)[8], co
 // inputs still give identical outputs (ties stay ties).
 // DBG != 0: timing-only diagnostic builds (outputs wrong by construction; tools/conv_bench.py conv_variant=11/21/41/51):
 //   1 = no LDS-DMA after the prologue, 2 = no MFMAs, 4 = every halo piece out of range, 5 = every A piece out of range
-template <typename T, int TAPS, int DBG = 0, bool GN = false, int MT = 6>
+template <typename T, int TAPS, int DBG = 0, bool GN = false, int MT = 6, typename OT = T>
 __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
   // MT = M tiles (of 16 couts) per wave: 6 -> 192-cout blocks (the EDM U-Net widths), 4 -> 128-cout blocks (classifier, SD VAE widths)
   static_assert(MT == 6 || MT == 4, "cout tile");
@@ -986,7 +994,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
     hc[nt] = ((pl >> 4) + bd) * hwid + (pl & 15) + bd;
   }
 
-  const bool bias_in_acc = kp.splits == 1 && kp.bias != nullptr;
+  const bool bias_in_acc = sizeof(OT) == 2 && kp.splits == 1 && kp.bias != nullptr;
 
   // ---- prologue: A_g(0), A_g(1), the halo of the first chunk (all pieces).  The launcher makes every K split a whole number of
   // chunks (nk % TAPS == 0, ks_begin % TAPS == 0).
@@ -1207,7 +1215,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
   __syncthreads();
   DTS_STAMP(2);
 
-  conv_epilogue<T, MT, NT, BM, BN, NTHR, H_OFF + 2 * H_BUF>(kp, acc, cm0, tm, (int)blockIdx.y, wm, wn, lrow, lq, smem, bias_in_acc, 0, 0, 0);
+  conv_epilogue<OT, MT, NT, BM, BN, NTHR, H_OFF + 2 * H_BUF>(kp, acc, cm0, tm, (int)blockIdx.y, wm, wn, lrow, lq, smem, bias_in_acc, 0, 0, 0);
   DTS_STAMP(3);
   DTS_STAMP_RT(5);
 }
@@ -1233,6 +1241,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvP kp)
     float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < SPLITS; ++s) { v[0] += q[s].x; v[1] += q[s].y; v[2] += q[s].z; v[3] += q[s].w; }      // fixed order
+    for (int r = 0; r < 4; ++r) v[r] *= kp.acc_scale;                                                          // (1 outside the split-precision mode)
     if (kp.bias) {
       const float4 bv = *reinterpret_cast<const float4*>(kp.bias + co);
       v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
@@ -1295,6 +1304,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_stats_kernel(const Con
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int pp = p0 + 16 * i;
+      for (int r = 0; r < 4; ++r) v[i][r] *= kp.acc_scale;
       v[i][0] += bv.x; v[i][1] += bv.y; v[i][2] += bv.z; v[i][3] += bv.w;
       if (bnc) { for (int r = 0; r < 4; ++r) v[i][r] += nb[r]; }
       if (res) {
@@ -1360,7 +1370,7 @@ int launch_reduce(const ConvP& q, bool with_stats, hipStream_t st) {
   }
 }
 
-template <typename T, int MT, int NT, int WM, int WN, bool PF, int STAGES>
+template <typename T, int MT, int NT, int WM, int WN, bool PF, int STAGES, typename OT = T>
 int launch_conv_staged(const ConvP& q, int nblk, int splits, hipStream_t st, ConvCall& call) {
   constexpr int NW = WM * WN;
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
@@ -1368,19 +1378,19 @@ int launch_conv_staged(const ConvP& q, int nblk, int splits, hipStream_t st, Con
   static bool attr_done[DTS_MAX_DEVICES] = {};            // the attribute is per DEVICE: a process that drives several GPUs sets it on each
   const int dev = current_device();
   if (!attr_done[dev]) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, MT, NT, WM, WN, PF, STAGES>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, MT, NT, WM, WN, PF, STAGES, OT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done[dev] = true;
   }
   if (call.ev_start != nullptr && call.ev_stop != nullptr)
-    hipExtLaunchKernelGGL((conv_igemm_kernel<T, MT, NT, WM, WN, PF, STAGES>), dim3(nblk, splits), dim3(64 * NW), lds, st, call.ev_start, call.ev_stop, 0, q);
+    hipExtLaunchKernelGGL((conv_igemm_kernel<T, MT, NT, WM, WN, PF, STAGES, OT>), dim3(nblk, splits), dim3(64 * NW), lds, st, call.ev_start, call.ev_stop, 0, q);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<T, MT, NT, WM, WN, PF, STAGES>), dim3(nblk, splits), dim3(64 * NW), lds, st, q);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, MT, NT, WM, WN, PF, STAGES, OT>), dim3(nblk, splits), dim3(64 * NW), lds, st, q);
   DTS_CHECK_LAUNCH("dts_conv2d");
   return DTS_OK;
 }
 
-template <typename T, int MT, int NT, int WM, int WN, bool PF>
+template <typename T, int MT, int NT, int WM, int WN, bool PF, typename OT = T>
 int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, ConvCall& call) {
   constexpr int BM = 16 * MT * WM, BN = 16 * NT * WN;
   constexpr int BKE = 8 * ET<T>::EPV;
@@ -1447,29 +1457,30 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, C
   int rc;
   if constexpr (sizeof(T) == 2 && MT % 2 == 0) {
     if (waves8) {
-      if (stages >= 3) rc = launch_conv_staged<T, MT / 2, NT, WM * 2, WN, PF, 3>(q, nblk, splits, st, call);
-      else rc = launch_conv_staged<T, MT / 2, NT, WM * 2, WN, PF, 2>(q, nblk, splits, st, call);
+      if (stages >= 3) rc = launch_conv_staged<T, MT / 2, NT, WM * 2, WN, PF, 3, OT>(q, nblk, splits, st, call);
+      else rc = launch_conv_staged<T, MT / 2, NT, WM * 2, WN, PF, 2, OT>(q, nblk, splits, st, call);
       if (rc != DTS_OK) return rc;
       if (splits > 1) {
         if (stats_in_reduce) q.stats = stats_req;
-        return launch_reduce<T>(q, stats_in_reduce, st);
+        return launch_reduce<OT>(q, stats_in_reduce, st);
       }
       return DTS_OK;
     }
   }
-  if (stages == 4) rc = launch_conv_staged<T, MT, NT, WM, WN, PF, (sizeof(T) == 2 ? 4 : 2)>(q, nblk, splits, st, call);
-  else if (stages == 3) rc = launch_conv_staged<T, MT, NT, WM, WN, PF, (sizeof(T) == 2 ? 3 : 2)>(q, nblk, splits, st, call);
-  else rc = launch_conv_staged<T, MT, NT, WM, WN, PF, 2>(q, nblk, splits, st, call);
+  // (the 4-deep ring exists for the A/B knob only, and only for OT = T)
+  if (stages == 4 && std::is_same<T, OT>::value) rc = launch_conv_staged<T, MT, NT, WM, WN, PF, (sizeof(T) == 2 ? 4 : 2)>(q, nblk, splits, st, call);
+  else if (stages >= 3) rc = launch_conv_staged<T, MT, NT, WM, WN, PF, (sizeof(T) == 2 ? 3 : 2), OT>(q, nblk, splits, st, call);
+  else rc = launch_conv_staged<T, MT, NT, WM, WN, PF, 2, OT>(q, nblk, splits, st, call);
   if (rc != DTS_OK) return rc;
   if (splits > 1) {
     if (stats_in_reduce) q.stats = stats_req;
-    return launch_reduce<T>(q, stats_in_reduce, st);
+    return launch_reduce<OT>(q, stats_in_reduce, st);
   }
   return DTS_OK;
 }
 
 // ---- ping-pong launcher: one block per (192- or 128-cout tile, 256-pixel tile[, K split]); 512 threads, 154 KB (MT = 6) / 130 KB (MT = 4) of LDS
-template <typename T, int TAPS, int DBG = 0, bool GN = false, int MT = 6>
+template <typename T, int TAPS, int DBG = 0, bool GN = false, int MT = 6, typename OT = T>
 int launch_conv_pp(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, ConvCall& call) {
   // 3x3 only: the kernel's TAPS == 1 form has a landing race with more than one channel chunk (see conv_pick_pp) and must not be launched
   static_assert(TAPS == 9, "conv_pp_kernel: only the 3x3 form is safe to launch");
@@ -1523,28 +1534,28 @@ int launch_conv_pp(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes
     static bool attr_done[DTS_MAX_DEVICES] = {};
     const int dev = current_device();
     if (!attr_done[dev]) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<T, TAPS, DBG, GN, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<T, TAPS, DBG, GN, MT, OT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_done[dev] = true;
     }
     if (call.ev_start != nullptr && call.ev_stop != nullptr)
-      hipExtLaunchKernelGGL((conv_pp_kernel<T, TAPS, DBG, GN, MT>), dim3(nblk, splits), dim3(512), lds, st, call.ev_start, call.ev_stop, 0, q);
+      hipExtLaunchKernelGGL((conv_pp_kernel<T, TAPS, DBG, GN, MT, OT>), dim3(nblk, splits), dim3(512), lds, st, call.ev_start, call.ev_stop, 0, q);
     else
-      hipLaunchKernelGGL((conv_pp_kernel<T, TAPS, DBG, GN, MT>), dim3(nblk, splits), dim3(512), lds, st, q);
+      hipLaunchKernelGGL((conv_pp_kernel<T, TAPS, DBG, GN, MT, OT>), dim3(nblk, splits), dim3(512), lds, st, q);
     DTS_CHECK_LAUNCH("dts_conv2d(ping-pong)");
     if (splits > 1) {
       if (stats_in_reduce) q.stats = stats_req;
-      return launch_reduce<T>(q, stats_in_reduce, st);
+      return launch_reduce<OT>(q, stats_in_reduce, st);
     }
     return DTS_OK;
   }
 }
 
-template <typename T, bool PF>
+template <typename T, bool PF, typename OT = T>
 int conv_dispatch_tile(const ConvP& p, int tile, hipStream_t st, float* ws, long long ws_bytes, ConvCall& call) {
   switch (tile) {
-    case 192: return launch_conv<T, 6, 4, 2, 2, PF>(p, st, ws, ws_bytes, call);
-    case 128: return launch_conv<T, 4, 4, 2, 2, PF>(p, st, ws, ws_bytes, call);
-    default: return launch_conv<T, 4, 4, 1, 4, PF>(p, st, ws, ws_bytes, call);
+    case 192: return launch_conv<T, 6, 4, 2, 2, PF, OT>(p, st, ws, ws_bytes, call);
+    case 128: return launch_conv<T, 4, 4, 2, 2, PF, OT>(p, st, ws, ws_bytes, call);
+    default: return launch_conv<T, 4, 4, 1, 4, PF, OT>(p, st, ws, ws_bytes, call);
   }
 }
 
@@ -1586,13 +1597,20 @@ int conv_pick_pp(bool f32, const ConvP& p) {
   return (auto_pp && blocks_pp >= 64) ? mt : 0;
 }
 
-template <typename T>
+template <typename T, typename OT = T>
 int conv_dispatch(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, ConvCall& call) {
   const int g_tile_override = dts_knob_get(DTS_KNOB_CONV_TILE);     // DTS_CONV_TILE=64|128|192 (tuning aid; only honoured when it divides cout)
   int tile = (p.cout % 192 == 0) ? 192 : (p.cout % 128 == 0 ? 128 : 64);    // measured: tools/conv_bench.py
   // f32 (parity mode): the 192-cout tile needs 256 VGPRs and still spills 36 bytes per lane to scratch; take the next tile down
   if (std::is_same<T, float>::value && tile == 192) tile = (p.cout % 128 == 0) ? 128 : 64;
   const int pp = conv_pick_pp(std::is_same<T, float>::value, p);
+  if constexpr (!std::is_same<T, OT>::value) {       // split-precision mode: the two shipped ping-pong forms and the implicit-GEMM forms, no knob variants
+    if (pp == 6) return launch_conv_pp<T, 9, 0, false, 6, OT>(p, st, ws, ws_bytes, call);
+    if (pp == 4) return launch_conv_pp<T, 9, 0, false, 4, OT>(p, st, ws, ws_bytes, call);
+    if (g_tile_override > 0 && p.cout % g_tile_override == 0) tile = g_tile_override;
+    if (p.taps == 9) return conv_dispatch_tile<T, true, OT>(p, tile, st, ws, ws_bytes, call);
+    return conv_dispatch_tile<T, false, OT>(p, tile, st, ws, ws_bytes, call);
+  }
   if (pp == 6) {
     const int variant = dts_knob_get(DTS_KNOB_CONV_VARIANT);
 #define DTS_PP(DBG_) launch_conv_pp<T, 9, DBG_>(p, st, ws, ws_bytes, call)
@@ -1693,7 +1711,7 @@ extern "C" int dts_conv2d(dts_conv_args* a, dts_stream s) {
   p.cout = a->cout; p.taps = a->ksize * a->ksize; p.up = a->up;
   const long long P = (long long)p.n * p.hout * p.wout;
   DTS_CHECK_ARG(P < (1ll << 30), "dts_conv2d: too many pixels");
-  p.P = (int)P; p.out_scale = a->out_scale; p.n_ct = p.n_pt = 0;
+  p.P = (int)P; p.out_scale = a->out_scale; p.acc_scale = a->acc_scale == 0.f ? 1.f : a->acc_scale; p.n_ct = p.n_pt = 0;
   p.splits = 1; p.ks_per_split = 0; p.partial = nullptr;
   p.w_shift = p.hw_shift = -1;
   {
@@ -1711,7 +1729,14 @@ extern "C" int dts_conv2d(dts_conv_args* a, dts_stream s) {
   int rc = DTS_OK;
   ConvCall call;
   call.ev_start = (hipEvent_t)a->ev_start; call.ev_stop = (hipEvent_t)a->ev_stop;
-  DTS_DISPATCH_DTYPE(a->dtype, rc = conv_dispatch<T>(p, st, (float*)a->workspace, (long long)a->workspace_bytes, call));
+  DTS_CHECK_ARG(p.acc_scale == 1.f || a->dtype == DTS_F16X3, "dts_conv2d: acc_scale is the split-precision mode's (DTS_F16X3)");
+  if (a->dtype == DTS_F16X3) {
+    // split precision: f16 operand planes on the 16-bit MFMA, f32 accumulate, f32 epilogue operands and output
+    DTS_CHECK_ARG(a->gn_coef == nullptr, "dts_conv2d: gn_coef is not available in the split-precision mode");
+    rc = conv_dispatch<f16_t, float>(p, st, (float*)a->workspace, (long long)a->workspace_bytes, call);
+  } else {
+    DTS_DISPATCH_DTYPE(a->dtype, rc = conv_dispatch<T>(p, st, (float*)a->workspace, (long long)a->workspace_bytes, call));
+  }
   a->stats_written = call.stats_written ? 1 : 0;
   return rc;
 }

@@ -509,6 +509,46 @@ extern "C" int dts_pack_conv_weight(const float* w, void* dst, int dtype, int O,
   });
   return DTS_OK;
 }
+// split-precision operand image (dts.h DTS_F16X3): row p of concat(x1, x2) -> hi | lo * 2^11 | hi, 8 channels (two float4 in, three 16-byte
+// stores out) per thread.  HBM-bound: 4 bytes read + 6 written per element.
+__global__ __launch_bounds__(256) void split3_f16_kernel(const float* __restrict__ x1, int c1, const float* __restrict__ x2, int c2,
+                                                          uint4* __restrict__ out, long long rows) {
+  const int C = c1 + c2, nch = C / 8;
+  const long long total = rows * nch;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const long long row = idx / nch;
+    const int ch = (int)(idx - row * nch), c0 = ch * 8;
+    const float* src = c0 < c1 ? x1 + row * c1 + c0 : x2 + row * c2 + (c0 - c1);
+    const float4 a = reinterpret_cast<const float4*>(src)[0], b = reinterpret_cast<const float4*>(src)[1];
+    const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    float hi[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      // hi = f16(x), round to nearest even (|x| >= 65520 becomes inf, as a plain f16 cast would).  The matrix cores flush f16 SUBNORMAL
+      // inputs (measured: tests/test_gpu_ops.py::test_conv2d_split_precision[tiny_values]), so (1) a hi below 2^-14 is dropped and the
+      // whole value goes into the lo plane, and (2) the lo plane carries lo * 2^11 -- the packed weights of that K segment carry 2^-11 --
+      // which keeps it a normal f16 number down to |x - hi| = 2^-25.  x - hi is exact in f32 (the residual of a rounding fits 13 bits).
+      float h = f16_bits_to_f32(f32_to_f16_bits(f[e]));
+      if (fabsf(h) < 6.103515625e-05f) h = 0.f;
+      hi[e] = h;
+      lo[e] = (f[e] - h) * 2048.0f;
+    }
+    const uint4 h = pack16<f16_t>(hi), l = pack16<f16_t>(lo);
+    uint4* o = out + row * (3 * nch) + ch;
+    o[0] = h; o[nch] = l; o[2 * nch] = h;
+  }
+}
+
+extern "C" int dts_split3_f16(const float* x1, int c1, const float* x2, int c2, void* out, int64_t rows, dts_stream s) {
+  DTS_CHECK_ARG(x1 && out && rows >= 0 && c1 > 0 && c1 % 8 == 0 && c2 >= 0 && c2 % 8 == 0, "dts_split3_f16: bad args (c1=%d c2=%d)", c1, c2);
+  DTS_CHECK_ARG(c2 == 0 || x2, "dts_split3_f16: c2 without x2");
+  if (rows == 0) return DTS_OK;
+  ST;
+  hipLaunchKernelGGL(split3_f16_kernel, dim3(grid1d(rows * ((c1 + c2) / 8))), dim3(256), 0, st, x1, c1, x2, c2, (uint4*)out, (long long)rows);
+  DTS_CHECK_LAUNCH("dts_split3_f16");
+  return DTS_OK;
+}
+
 extern "C" int dts_cast_from_f32(const float* src, void* dst, int dtype, int64_t count, dts_stream s) {
   DTS_CHECK_ARG(src && dst && count >= 0, "dts_cast_from_f32: bad args");
   if (count == 0) return DTS_OK;

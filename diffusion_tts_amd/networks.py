@@ -46,7 +46,8 @@ class EDMPrecond:
             raise RuntimeError('EDMPrecond (HIP) needs a GPU: there is no CPU fallback in this package')
         self.cfg = cfg
         self.device = torch.device(device)
-        self.dtype = dtype
+        self.dtype = dtype                               # compute mode: float32 (parity) | bfloat16 | float16 | ops.F16X3 (split precision)
+        self.act_dtype = ops.act_dtype(dtype)            # storage type of the activations
         self.img_resolution, self.img_channels, self.label_dim = cfg.img_resolution, cfg.img_channels, cfg.label_dim
         self.sigma_min, self.sigma_max, self.sigma_data = cfg.sigma_min, cfg.sigma_max, cfg.sigma_data
         self.use_fp16 = dtype == torch.float16
@@ -205,9 +206,9 @@ class EDMPrecond:
         """F_x = model(c_in*x, c_noise, labels): xin f32 NCHW -> f32 NCHW."""
         n = xin.shape[0]
         emb = self._embedding(c_noise, class_labels, n)
-        e = ops.cast_from_f32(emb, self.dtype)
+        e = ops.cast_from_f32(emb, self.act_dtype)
         aff = ops.conv2d(e.view(1, n, 1, -1), self.aff_w, self.aff_b).view(n, self.aff_total)
-        x = ops.conv_in3(xin, self.conv_in_w, self.conv_in_b, self.enc[0].cout, self.dtype)
+        x = ops.conv_in3(xin, self.conv_in_w, self.conv_in_b, self.enc[0].cout, self.act_dtype)
         skips = [x]
         for b in self.enc[1:]:
             x = self._block(b, x, None, aff)

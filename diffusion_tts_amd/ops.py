@@ -5,12 +5,41 @@ no CPU path here (the CPU restatement lives in oracle/ and is test infrastructur
 Activation tensors are NHWC: shape [n, h, w, c], contiguous, dtype float32 / bfloat16 / float16.
 """
 import ctypes as C
+import math
 
 import torch
 
 from . import _lib as L
 
 _DT = {torch.float32: L.DTS_F32, torch.bfloat16: L.DTS_BF16, torch.float16: L.DTS_F16}
+
+# The split-precision compute mode (dts.h DTS_F16X3): activations are float32 tensors and every kernel but the convolutions is the
+# float32 (parity-mode) one; the convolutions -- 99.9 % of the FLOPs -- run on the 16-bit matrix cores over the f16 split image of
+# their input (hi | lo | hi) against weights packed as hi | hi | lo, f32 accumulate: ~2^-22 products instead of f16's 2^-11, at a
+# third of the f16 rate instead of the f32 matrix instruction's sixteenth.  Accepted wherever a compute dtype is.
+F16X3 = 'f16x3'
+
+
+def act_dtype(dtype):
+    """storage type of the activations of a network computing in `dtype`"""
+    return torch.float32 if dtype == F16X3 else dtype
+
+
+def dtype_name(dtype):
+    return dtype if isinstance(dtype, str) else {torch.float32: 'f32', torch.bfloat16: 'bf16', torch.float16: 'f16'}[dtype]
+
+
+class X3Weight:
+    """A conv weight packed for the split-precision mode: `packed` [O][kh][kw][3*I] float16 = hi | hi * 2^-11 | lo of w * 2^k along the
+    input channels (k chosen per layer so that 2^13 < max|w| * 2^k <= 2^14: the lo parts of all weights that matter are normal f16
+    numbers; the matrix cores flush subnormal inputs), `acc_scale` = 2^-k.  The middle segment meets the activations' lo * 2^11 plane."""
+
+    def __init__(self, packed, acc_scale, shape):
+        self.packed, self.acc_scale, self.shape = packed, float(acc_scale), tuple(shape)
+        self.device, self.dtype = packed.device, F16X3
+
+    def numel(self):
+        return self.packed.numel()
 
 
 def dt_code(dtype):
@@ -81,6 +110,15 @@ def pack_conv_weight(w, dtype, out_perm=None):
         w = w.unsqueeze(-1)
     w = w.contiguous()
     O, I, kh, kw = w.shape
+    if dtype == F16X3:                    # load-time preparation in float32 on the device: exact scaling, two roundings
+        wp = w if out_perm is None else w[out_perm.long()]
+        amax = float(wp.abs().max())
+        k = 0 if amax == 0.0 else max(-24, min(24, int(math.floor(math.log2(16384.0 / amax)))))
+        ws = (wp * (2.0 ** k)).permute(0, 2, 3, 1).contiguous()            # [O][kh][kw][I], exact (power of two)
+        hi = ws.to(torch.float16)
+        lo = (ws - hi.to(torch.float32)).to(torch.float16)
+        hi_s = (hi.to(torch.float32) * 2.0 ** -11).to(torch.float16)       # meets the activations' lo plane, which carries lo * 2^11 (dts_split3_f16)
+        return X3Weight(torch.cat([hi, hi_s, lo], dim=-1).contiguous(), 2.0 ** -k, (O, kh, kw, I))
     out = torch.empty((O, kh, kw, I), dtype=dtype, device=w.device)
     _call('dts_pack_conv_weight', _ptr(w, 'w', torch.float32), _ptr(out), dt_code(dtype), O, I, kh, kw,
           _ptr(out_perm, 'perm', torch.int32))
@@ -113,6 +151,8 @@ def conv_kernel(x1, w, x2=None, up=False, residual=None, gn_coef=None):
     """Which kernel ops.conv2d launches for these arguments: 0 = 4-wave implicit GEMM, 6 / 4 = ping-pong kernel with 192- / 128-cout
     blocks (dts_conv_kernel; measurement aid for bench.py)."""
     a = _conv_args(x1, w, x2, up)
+    if isinstance(w, X3Weight):           # the launch sees one 16-bit source of 3*(c1+c2) channels
+        a.c1, a.c2, a.dtype = 3 * (a.c1 + a.c2), 0, L.DTS_F16X3
     a.residual = _ptr(residual)
     a.gn_coef = _ptr(gn_coef, 'gn_coef', torch.float32)
     return int(L.load().dts_conv_kernel(C.byref(a)))
@@ -136,12 +176,20 @@ def conv2d(x1, w, bias=None, *, x2=None, bias_nc=None, residual=None, up=False, 
     if cin != c1 + c2 or kh != kw:
         raise ValueError(f'conv2d: weight {tuple(w.shape)} does not match inputs ({c1}+{c2})')
     ho, wo = (2 * hin, 2 * win) if up else (hin, win)
+    x3 = isinstance(w, X3Weight)
+    if x3 and (x1.dtype != torch.float32 or gn_coef is not None):
+        raise ValueError('conv2d: a split-precision weight takes float32 activations (and no fused input GroupNorm)')
     if out is None:
         out = torch.empty((n, ho, wo, cout), dtype=x1.dtype, device=x1.device)
     a = L.ConvArgs()
-    a.x1, a.c1 = _ptr(x1, 'x1'), c1
-    a.x2, a.c2 = _ptr(x2, 'x2', x1.dtype), c2
-    a.w = _ptr(w, 'w', x1.dtype)
+    if x3:      # the conv reads the f16 split image hi | lo | hi of concat(x1, x2); epilogue operands and output stay float32
+        xs = split3_f16(x1, x2)
+        a.x1, a.c1, a.x2, a.c2 = _ptr(xs), 3 * (c1 + c2), None, 0
+        a.w, a.acc_scale = _ptr(w.packed, 'w', torch.float16), w.acc_scale
+    else:
+        a.x1, a.c1 = _ptr(x1, 'x1'), c1
+        a.x2, a.c2 = _ptr(x2, 'x2', x1.dtype), c2
+        a.w = _ptr(w, 'w', x1.dtype)
     a.bias = _ptr(bias, 'bias', torch.float32)
     a.bias_nc, a.ld_bias_nc = _rows(bias_nc, 'bias_nc', x1.dtype)
     a.residual = _ptr(residual, 'residual', x1.dtype)
@@ -149,7 +197,7 @@ def conv2d(x1, w, bias=None, *, x2=None, bias_nc=None, residual=None, up=False, 
         raise ValueError(f'conv2d: residual shape {tuple(residual.shape)} != {(n, ho, wo, cout)}')
     a.out = _ptr(out, 'out', x1.dtype)
     a.n, a.hin, a.win, a.cout, a.ksize = n, hin, win, cout, kh
-    a.up, a.out_scale, a.dtype = int(up), float(out_scale), dt_code(x1.dtype)
+    a.up, a.out_scale, a.dtype = int(up), float(out_scale), (L.DTS_F16X3 if x3 else dt_code(x1.dtype))
     ws = _conv_workspace(x1.device)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     st = None
@@ -164,6 +212,15 @@ def conv2d(x1, w, bias=None, *, x2=None, bias_nc=None, residual=None, up=False, 
         a.gn_coef, a.gn_silu = _ptr(gn_coef, 'gn_coef', torch.float32), int(gn_silu)
     _call('dts_conv2d', C.byref(a))
     out._gn_stats = st if (st is not None and a.stats_written) else None
+    return out
+
+
+def split3_f16(x1, x2=None):
+    """float32 NHWC [n,h,w,c1] (+ [n,h,w,c2]) -> float16 [n,h,w,3*(c1+c2)] = hi | lo | hi of the channel concat (dts_split3_f16)."""
+    n, h, w, c1 = x1.shape
+    c2 = 0 if x2 is None else x2.shape[-1]
+    out = torch.empty((n, h, w, 3 * (c1 + c2)), dtype=torch.float16, device=x1.device)
+    _call('dts_split3_f16', _ptr(x1, 'x1', torch.float32), c1, _ptr(x2, 'x2', torch.float32), c2, _ptr(out), n * h * w)
     return out
 
 

@@ -383,7 +383,7 @@ def _mcts(L: _Loop, t_steps, x_next, labels, p, pre):
                         # launchers choose the split-K factor / launch form from the row count (another fixed f32 summation order).
                         # The f32 parity mode therefore runs its rollouts unpadded; padding rows are not counted as evaluations.
                         ka = len(act)
-                        pad = MCTS_PAD_ROLLOUTS and ka <= 16 and getattr(L.net, 'dtype', None) != torch.float32
+                        pad = MCTS_PAD_ROLLOUTS and ka <= 16 and getattr(L.net, 'dtype', None) not in (torch.float32, ops.F16X3)
                         kp = -(-ka // 4) * 4 if pad else ka
                         if kp > ka:
                             xa = torch.cat([xa, xa[:1].expand(kp - ka, *xa.shape[1:])], dim=0)
@@ -452,7 +452,7 @@ def generate_image_grid(
     L = _Loop(net, device, num_steps, S_churn, S_min, S_max, S_noise, scale_fn, shards)
     # eps-greedy: the reference re-runs step() at batch 1 for the final pivot of each timestep (edm/main.py:860) although
     # that row was just computed in the last candidate batch.  Throughput modes reuse it; parity mode recomputes.
-    L.reuse_winner = (compute_dtype != torch.float32) if reuse_winner is None else bool(reuse_winner)
+    L.reuse_winner = (compute_dtype not in (torch.float32, ops.F16X3)) if reuse_winner is None else bool(reuse_winner)
     L.record_noises = bool(record_noises)
     x0 = (latents.to(torch.float64).cpu() * t_steps[0]).to(device).contiguous()       # edm/main.py:99
     labels = None if class_labels is None else class_labels.to(device, torch.float32).contiguous()

@@ -27,12 +27,21 @@ extern "C" {
 
 typedef void* dts_stream;
 
-enum dts_dtype { DTS_F32 = 0, DTS_BF16 = 1, DTS_F16 = 2 };
+enum dts_dtype { DTS_F32 = 0, DTS_BF16 = 1, DTS_F16 = 2,
+                 /* dts_conv2d only: SPLIT PRECISION on the 16-bit matrix cores.  Activations and the epilogue operands (bias_nc, residual,
+                    out) are f32 tensors; the conv's input is their split image from dts_split3_f16 -- x1 = [n][h][w][3*C] f16 holding
+                    hi | lo * 2^11 | hi with hi = f16(x), lo = x - hi -- and the packed weight is [cout][taps][3*C] f16 =
+                    hi | hi * 2^-11 | lo of w * 2^k (acc_scale = 2^-k; the powers of two keep every part a NORMAL f16 number: the matrix
+                    cores flush subnormal inputs), so ONE 16-bit MFMA K loop of three times the length accumulates, in f32,
+                    x_hi*w_hi + x_lo*w_hi + x_hi*w_lo: products exact to ~2^-22 (f16 x f16 carries 22 bits) against 2^-24 of the f32
+                    matrix instruction, which runs at 1/16 of the 16-bit rate.  The mode between the f32 parity mode and the 16-bit
+                    throughput modes (edm/main.py:842 argmax over rewards that differ by 1e-7). */
+                 DTS_F16X3 = 3 };
 enum dts_status { DTS_OK = 0, DTS_ERR_ARG = -1, DTS_ERR_LAUNCH = -2, DTS_ERR_UNSUPPORTED = -3 };
 
-#define DTS_ABI_VERSION 107        /* bumped with every change of a signature or of dts_conv_args (101: ev_start/ev_stop; 102: tuning knobs; 103: dts_cosine_rows; 104: dts_nchw_to_nhwc_pad,
+#define DTS_ABI_VERSION 108        /* bumped with every change of a signature or of dts_conv_args (101: ev_start/ev_stop; 102: tuning knobs; 103: dts_cosine_rows; 104: dts_nchw_to_nhwc_pad,
                                      105: dts_conv_args.gn_coef / gn_silu, dts_conv_fuses_gn;
-                                     head dim 512 in dts_attention; 106: dts_conv_kernel, 128-cout ping-pong blocks; 107: dts_resample_u8, dts_lut_u8_f32) */
+                                     head dim 512 in dts_attention; 106: dts_conv_kernel, 128-cout ping-pong blocks; 107: dts_resample_u8, dts_lut_u8_f32; 108: DTS_F16X3, dts_conv_args.acc_scale, dts_split3_f16) */
 int dts_version(void);            /* == DTS_ABI_VERSION of the build; a binding must refuse any other value */
 const char* dts_last_error(void);
 /* Tuning knobs (measurement aid; a knob only selects between kernels / block orders / ring depths that give correct results -- the
@@ -82,6 +91,8 @@ typedef struct dts_conv_args {
                                      normalised tensor is never written (networks.py:168,173-175 feeding conv0 / conv1).  Only launches
                                      for which dts_conv_fuses_gn() returns 1 accept it; padding stays zero (the reference pads AFTER the norm) */
   int32_t gn_silu;                /* 1: act = SiLU, 0: identity */
+  float acc_scale;                /* DTS_F16X3 only (0 = 1): out = (conv * acc_scale + bias + bias_nc + residual) * out_scale; undoes the power of
+                                     two the packed split-precision weights carry */
 } dts_conv_args;
 /* 1 if dts_conv2d would apply a->gn_coef inside the conv for this shape / dtype (3x3, cout % 192 == 0, 16-bit, square power-of-two
  * images >= 16, whole 256-pixel tiles, no fused upsample), else 0: the caller then runs dts_gn_apply first. */
@@ -139,6 +150,10 @@ int dts_edm_precond_in(const double* x, const double* sigma, int nsigma, float s
                        float* xin, float* coef, int n, int chw, dts_stream s);
 /* D = c_skip*f32(x) + c_out*F  (f32, NCHW) */
 int dts_edm_precond_out(const double* x, const float* F, const float* coef, float* D, int n, int chw, dts_stream s);
+/* split-precision operand image for dts_conv2d(dtype = DTS_F16X3): out[p][0:C] = hi, [C:2C] = lo * 2^11, [2C:3C] = hi of
+ * concat(x1, x2)[p][:] (f32 rows of c1 / c2 channels, x2 may be NULL with c2 = 0; C = c1 + c2, multiples of 8), hi = f16(x) (0 when that
+ * would be subnormal), lo = f16((x - hi) * 2^11). */
+int dts_split3_f16(const float* x1, int c1, const float* x2, int c2, void* out, int64_t rows, dts_stream s);
 /* f32 -> dtype cast of a dense array (embedding -> activation dtype) and back */
 int dts_cast_from_f32(const float* src, void* dst, int dtype, int64_t count, dts_stream s);
 int dts_cast_to_f32(const void* src, int dtype, float* dst, int64_t count, dts_stream s);

@@ -94,6 +94,73 @@ def test_conv2d(ops, dtype, case):
     assert rel_err(got, ref) < TOL[dtype], (case, rel_err(got, ref))
 
 
+@pytest.mark.parametrize('case', ['3x3', '1x1', 'up', 'cat', 'full_epilogue', 'ragged', 'tile192', 'tile576', 'splitk_full', 'pp192', 'pp128',
+                                  'pp_res', 'tiny_values', 'huge_weights'])
+def test_conv2d_split_precision(ops, case):
+    """dtype F16X3: float32 activations, convolution on the 16-bit matrix cores over the f16 split image hi | lo | hi against weights packed
+    hi | hi | lo (dts.h).  Products carry ~22 bits: the result must sit at the f32 parity kernel's distance from the f64 reference (not at
+    f16's 2^-11), on every launch form: implicit GEMM (4 / 8 waves, split K + reduce), ping-pong with 192- and 128-cout blocks, concat,
+    fused upsample, full epilogue (bias, per-sample bias, residual, scale), ragged tiles; operands whose lo parts are f16-subnormal."""
+    gen = g(5)
+    n, h, w, c1, c2, cout, k, up = 2, 8, 8, 64, 0, 64, 3, False
+    xs, wsc = 1.0, 1.0
+    if case == '1x1':
+        k = 1
+    if case == 'up':
+        up = True
+    if case == 'cat':
+        c1, c2, k = 128, 64, 1
+    if case == 'ragged':
+        n, h, w = 3, 5, 7
+    if case == 'tile192':
+        cout = 192
+    if case == 'tile576':
+        n, h, w, c1, cout = 1, 16, 16, 128, 576
+    if case == 'splitk_full':
+        n, h, w, c1, cout = 1, 8, 8, 256, 128
+    if case in ('pp192', 'pp_res'):
+        n, h, w, c1, cout = 4, 32, 32, 128, 192          # 16 blocks: the launcher takes the ping-pong kernel when forced below
+    if case == 'pp128':
+        n, h, w, c1, cout = 4, 32, 32, 64, 128
+    if case == 'tiny_values':
+        xs = 2.0 ** -9                                    # |x| ~ 2e-3: every lo part is an f16 subnormal
+    if case == 'huge_weights':
+        wsc = 300.0                                       # max |w| ~ 100: the pack scales DOWN (k < 0)
+    x1 = torch.randn(n, c1, h, w, generator=gen) * xs
+    x2 = torch.randn(n, c2, h, w, generator=gen) * xs if c2 else None
+    wt = torch.randn(cout, c1 + c2, k, k, generator=gen) / math.sqrt((c1 + c2) * k * k) * wsc
+    bias = torch.randn(cout, generator=gen) * xs
+    xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+    ref = F.conv2d(F.interpolate(xin.double(), scale_factor=2, mode='nearest') if up else xin.double(), wt.double(), bias.double(), padding=k // 2)
+    kw, kw32 = {}, {}
+    if case in ('full_epilogue', 'splitk_full', 'pp_res'):
+        bnc = torch.randn(n, cout, generator=gen)
+        res = torch.randn(n, cout, h, w, generator=gen)
+        ref = (ref + bnc.double()[:, :, None, None] + res.double()) * 0.70710678
+        kw = dict(bias_nc=bnc.to(DEV), residual=to_nhwc(ops, res, torch.float32), out_scale=0.70710678)
+    from diffusion_tts_amd import _lib
+    if case.startswith('pp'):
+        _lib.set_tuning('conv_variant', 1)
+    try:
+        x1d, x2d = to_nhwc(ops, x1, torch.float32), (None if x2 is None else to_nhwc(ops, x2, torch.float32))
+        w3 = ops.pack_conv_weight(wt.to(DEV), ops.F16X3)
+        assert tuple(w3.shape) == (cout, k, k, c1 + c2) and w3.packed.shape[-1] == 3 * (c1 + c2) and w3.packed.dtype == torch.float16
+        if case.startswith('pp'):
+            assert ops.conv_kernel(x1d, w3) in (4, 6)
+        out = ops.conv2d(x1d, w3, bias.to(DEV), x2=x2d, up=up, gn_stats=True, **kw)
+        out32 = ops.conv2d(x1d, ops.pack_conv_weight(wt.to(DEV), torch.float32), bias.to(DEV), x2=x2d, up=up, gn_stats=True, **kw)
+    finally:
+        _lib.set_tuning('conv_variant', -1)
+    assert out.dtype == torch.float32
+    got, got32 = from_nhwc(ops, out).double(), from_nhwc(ops, out32).double()
+    scale = float(ref.abs().max())
+    e3, e32 = float((got - ref).abs().max()) / scale, float((got32 - ref).abs().max()) / scale
+    print(f'split precision {case}: rel err {e3:.2e} (f32 kernel {e32:.2e})')
+    assert e3 < 3e-6 and e3 < 16 * max(e32, 1e-7), (case, e3, e32)
+    if out._gn_stats is not None and out32._gn_stats is not None:      # GroupNorm strip statistics of the f32 outputs
+        assert torch.allclose(out._gn_stats, out32._gn_stats, rtol=1e-4, atol=1e-4 * max(1.0, scale) ** 2)
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_conv2d_big_tiles(ops, dtype):
     """cout % 128 == 0 and >= 32768 pixels selects the 128x128 block tile."""
