@@ -34,10 +34,18 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3,       # dense MFMA peaks, MI355X_MICROARCH.md
+               'f16x3': 2500.0}   # split precision runs on the f16 matrix instruction: ALGORITHMIC FLOPs (one per MAC pair, not its three passes) over that peak
+DTYPE_NAMES = ['bf16', 'f16', 'f32', 'f16x3']
+
+
+def torch_dtype(name):
+    import torch
+    from diffusion_tts_amd import ops
+    return {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32, 'f16x3': ops.F16X3}[name]
 GFLOP_PER_EVAL = {'adm64': 219.33, 'ddpmpp32': 42.38}             # BASELINE.md section 2 / SURVEY.md 8(d)
 CLS_GFLOP_PER_IMG = 38.16
-TRAFFIC_PROFILE = 'profiles/r03_hbm_traffic_pmc.json'             # written by tools/pmc_traffic.py from the rocprofv3 --pmc passes
+TRAFFIC_PROFILE = 'profiles/r04_hbm_traffic_pmc.json'             # written by tools/pmc_traffic.py from the rocprofv3 --pmc passes
 
 _T0 = time.perf_counter()
 
@@ -53,7 +61,7 @@ def parse(argv=None):
     ap.add_argument('--steps', type=int, default=None)
     ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--workload', default='adm64_eps_greedy', choices=['adm64_eps_greedy', 'ddpmpp32_rejection', 'adm64_mcts'])
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f32'])
+    ap.add_argument('--dtype', default='bf16', choices=DTYPE_NAMES, help='f32 = parity mode on the f32 MFMA; f16x3 = split precision on the 16-bit MFMA (near-f32 rewards)')
     ap.add_argument('--candidates', type=int, default=None, help='candidates in total (strong, default 64) or per GPU (weak)')
     ap.add_argument('--scaling', default='strong', choices=['weak', 'strong'])
     ap.add_argument('--scorer', default='imagenet', choices=['imagenet', 'brightness'])
@@ -137,6 +145,17 @@ def sigma_steps():
     return torch.cat([t, torch.zeros(1, dtype=torch.float64)])
 
 
+def cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for ln in f:
+                if ln.lower().startswith('model name'):
+                    return ln.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def oracle_iteration(sample_n, seed=0):
     """The oracle (CPU restatement of the reference, fp32 torch-CPU ops) on this box's host cores: ONE epsilon-greedy iteration
     (sigma step 5) over `sample_n` candidates = 2*sample_n ADM-64 denoiser rows + sample_n classifier images.  Returns the timing
@@ -168,7 +187,7 @@ def oracle_iteration(sample_n, seed=0):
     best = int(sc.argmax())
     dt = time.perf_counter() - t0
     rec = {'value': round(2 * sample_n / dt, 3), 'unit': 'candidate U-Net steps/sec', 'cores': torch.get_num_threads(),
-           'kind': 'port', 'seconds': round(dt, 2),
+           'kind': 'port', 'seconds': round(dt, 2), 'cpu_model': cpu_model(),
            'sample': f'1 eps-greedy iteration over {sample_n} candidates of the same workload: {2 * sample_n} ADM-64 '
                      f'denoiser rows + {sample_n} classifier images, fp32 torch-CPU oracle'}
     return rec, dict(x=x, eps=eps, lab=lab, rewards=sc.float(), best=best)
@@ -244,7 +263,8 @@ def conv_roofline(a, run_once, reps, dtype_name, value_per_gpu, gflop_per_eval, 
             doc = json.load(f)
         if a.workload == 'adm64_eps_greedy' and dtype_name == 'bf16' and a.candidates == 64 and a.gpus == 1:
             traffic = round(doc['kernels_by_family'][dom_family]['hbm_bytes_per_launch'])
-            tsrc = f'static, from {TRAFFIC_PROFILE} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; not measured in this run)'
+            tsrc = (f'static, from {TRAFFIC_PROFILE} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of this command, collected at commit '
+                    f'{doc.get("collected_at_commit", "unknown")}; counters cannot be read from inside the process, so NOT measured in this run)')
     except Exception:
         pass
     # the DOMINANT kernel = the conv kernel with the most time in the step (conv_pp_kernel on the ADM workload: the 3x3 layers); its
@@ -390,7 +410,7 @@ def scorer_dtype(dtype):
     return torch.float16 if dtype == torch.bfloat16 else dtype
 
 
-def build_adm(job, dtype, with_scorer=True, scorer_name='imagenet', sd=None):
+def build_adm(job, dtype, with_scorer=True, scorer_name='imagenet', sd=None, head_scale=None):
     import warnings
     from diffusion_tts_amd import init as dinit
     from diffusion_tts_amd.config import adm_imagenet64
@@ -404,7 +424,14 @@ def build_adm(job, dtype, with_scorer=True, scorer_name='imagenet', sd=None):
     if with_scorer:
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
-            scorer = ImageNetScorer(device=job.dev, compute_dtype=scorer_dtype(dtype), seed=1) if scorer_name == 'imagenet' else BrightnessScorer()
+            if scorer_name != 'imagenet':
+                scorer = BrightnessScorer()
+            elif head_scale is None:
+                scorer = ImageNetScorer(device=job.dev, compute_dtype=scorer_dtype(dtype), seed=1)
+            else:       # the decidable fixture: same draws, output head x head_scale (init.scale_classifier_head)
+                from diffusion_tts_amd.config import ClassifierConfig
+                csd, _ = dinit.refill_degenerate(dinit.classifier_state_dict(ClassifierConfig(), 1), 1)
+                scorer = ImageNetScorer(weights=dinit.scale_classifier_head(csd, head_scale), device=job.dev, compute_dtype=scorer_dtype(dtype))
     return net, scorer, sd
 
 
@@ -541,6 +568,58 @@ def e2e_leg(job, net, scorer, dtype):
     return {'e2e_evals_per_s': round(best, 1), 'e2e_rows': res['net_rows'], 'e2e_seconds_per_image': round(res['net_rows'] / best, 3)}
 
 
+def free_running_vs_f32(job, nets):
+    """One FREE-RUNNING config-3 search (generate_image_grid, eps-greedy N = 64 K = 4, 18 sigma steps, the same host RNG) per compute
+    mode, compared with the f32 parity mode's: how many of the 72 selections coincide, where the first differing selection is, and
+    max |x_final - x_final(f32)| (north_star: final images within 1e-3 abs).  A 16-bit search that picks another near-tied candidate
+    once follows another trajectory from there on, so its final image is a different sample: the figure says how different."""
+    import torch
+    from diffusion_tts_amd.sampler import SamplingMethod, generate_image_grid
+    from diffusion_tts_amd.hashing import seed0_scale
+    lat = torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(3))
+    lab = torch.eye(1000)[torch.tensor([5])]
+    res = {}
+    for name, (net, scorer) in nets.items():
+        r = generate_image_grid(net, None, lat, lab, seed=0, gridw=1, gridh=1, device=job.dev, num_steps=18, S_churn=40, S_min=0.05,
+                                S_max=50, S_noise=1.003, sampling_method=SamplingMethod.EPS_GREEDY,
+                                sampling_params=dict(scorer=scorer, N=64, K=4, lambda_param=0.15, eps=0.4), scale_fn=seed0_scale,
+                                compute_dtype=torch_dtype(name), reuse_winner=False, verbose=False)
+        res[name] = (r['x'].double().cpu(), [int(s_[0]) for s_ in r['selected']], float(r['final_scores'][0]))
+    out = {'search': 'config 3 end to end (eps-greedy N=64 K=4, 18 sigma steps, seed 0), every mode from the same host RNG; reference = f32 parity mode',
+           'f32_final_score': res['f32'][2]}
+    for name in nets:
+        if name == 'f32':
+            continue
+        x, sel, sc = res[name]
+        same = [int(a_ == b_) for a_, b_ in zip(sel, res['f32'][1])]
+        first = same.index(0) if 0 in same else None
+        out[name] = {'max_abs_x_final_vs_f32': float(f'{float((x - res["f32"][0]).abs().max()):.3e}'), 'same_selections': f'{sum(same)}/{len(same)}',
+                     'first_differing_selection': first, 'final_score': sc}
+    return out
+
+
+def parity_mode_records(a, job, nets):
+    """The timed region of the headline (one eps-greedy iteration over N = 64 candidates) in the modes that meet the north star's tolerance:
+    the f32 parity mode (v_mfma_f32_16x16x4_f32, peak 157.3 TFLOP/s) and the split-precision mode f16x3 (16-bit MFMA, three passes)."""
+    out = {}
+    for name in ('f32', 'f16x3'):
+        net, scorer = nets[name]
+        it = EpsGreedyIteration(job, net, scorer, 64)
+        for s_ in range(3):
+            it(s_)
+        steps = 4 if name == 'f32' else 10
+        dt = job.timed(it, steps, 1)
+        v = 2 * 64 * steps / dt
+        out[name] = {'value': round(v, 2), 'unit': 'candidate U-Net steps/sec', 'ms_per_step': round(dt / steps * 1e3, 3), 'steps': steps,
+                     'config': f'{name} denoiser + {name} classifier, N=64, graph replay',
+                     'roofline': {'bound': 'mfma', 'achieved': round(v * GFLOP_PER_EVAL['adm64'] / 1e3, 1), 'peak': PEAK_TFLOPS[name], 'unit': 'TFLOP/s',
+                                  'frac': round(v * GFLOP_PER_EVAL['adm64'] * 1e9 / (PEAK_TFLOPS[name] * 1e12), 4), 'traffic': None,
+                                  'kernel': 'whole step (denoiser FLOPs only, algorithmic: 219.33 GFLOP per evaluation)'}}
+        del it
+        log(f"parity mode {name}: {out[name]['value']} evals/s, {out[name]['ms_per_step']} ms/step")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 def sub_records(a, job, net, scorer, dtype, sd):
     """The other numbers DESIGN.md quotes, measured in the SAME driver-run process as the headline (each with its own ms_per_step and
@@ -639,7 +718,7 @@ def sd_beam_record(job, steps=4, B=4, N=16):
 
 def run_eps_greedy(a, job):
     import torch
-    dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[a.dtype]
+    dtype = torch_dtype(a.dtype)
     world, rank = job.world, job.rank
     net, scorer, sd = build_adm(job, dtype, scorer_name=a.scorer)
     log('denoiser + scorer packed on device')
@@ -651,9 +730,10 @@ def run_eps_greedy(a, job):
         it(s)
     torch.cuda.synchronize(job.dev)
     log(f'state resident; {it.nl} of {n_total} candidates on this rank; forwards captured ({net._graphs.captures} graphs)')
-    evals0 = net.evals
+    evals0, replays0 = net.evals, net._graphs.replays + 2 * a.warmup
     dt = job.timed(it, a.steps, a.warmup)
     rows_local = net.evals - evals0
+    graph_replays = net._graphs.replays - replays0
     value = 2 * n_total * a.steps / dt
     log(f'timed region: {dt:.3f}s for {a.steps} steps -> {value:.1f} evals/s')
 
@@ -692,16 +772,28 @@ def run_eps_greedy(a, job):
         extra['cpu_baseline'] = cpu
         if orc is not None and not a.no_parity and a.scorer == 'imagenet':
             nets = {a.dtype: (net, scorer)}
-            for name, dt_ in (('f32', torch.float32), ('f16', torch.float16), ('bf16', torch.bfloat16)):
+            modes = ('f32', 'f16x3', 'f16', 'bf16')
+            for name in modes:
                 if name not in nets:
-                    n_, s_, _ = build_adm(job, dt_, sd=sd)
+                    n_, s_, _ = build_adm(job, torch_dtype(name), sd=sd)
                     nets[name] = (n_, s_)
             want_sub = not a.no_subrecords and a.candidates == 64
-            extra['parity'] = parity_leg(job, orc, {k: nets[k] for k in ('f32', 'f16', 'bf16')}, short_agreement=not want_sub)
+            extra['parity'] = parity_leg(job, orc, {k: nets[k] for k in modes}, short_agreement=not want_sub)
             log('parity leg done')
             if want_sub:       # index agreement as a RATE: one whole config-3 search, teacher-forced on the f32 pivots
-                extra['parity']['index_agreement'] = teacher_forced_agreement(job, {k: nets[k] for k in ('f32', 'f16', 'bf16')}, n=64)
+                extra['parity']['index_agreement'] = teacher_forced_agreement(job, {k: nets[k] for k in modes}, n=64)
                 log(f"whole-search index agreement: {extra['parity']['index_agreement']}")
+                # the same on the second fixture: classifier output head x 20 (logit std ~3.4, init.scale_classifier_head)
+                from diffusion_tts_amd import init as dinit
+                hs = dinit.HEAD_SCALE_DECIDABLE
+                nets_h = {k: (nets[k][0], build_adm(job, torch_dtype(k), sd=sd, head_scale=hs)[1]) for k in modes}
+                extra['parity']['index_agreement_scaled_head'] = dict(teacher_forced_agreement(job, nets_h, n=64), head_scale=hs,
+                    fixture='same constructors and seeds, AttentionPool2d.c_proj x head_scale in oracle and build alike')
+                log(f"whole-search index agreement, scaled head: {extra['parity']['index_agreement_scaled_head']}")
+                del nets_h
+                extra['parity']['free_running_vs_f32'] = free_running_vs_f32(job, {k: nets[k] for k in modes})
+                log(f"free-running searches vs f32: {extra['parity']['free_running_vs_f32']}")
+                extra['parity_modes'] = parity_mode_records(a, job, nets)
             # the same timed region in the other 16-bit type (f16 is the reference's own CUDA dtype, networks.py:658): both throughput
             # figures and both index-agreement figures then sit in ONE driver-run record
             other = 'f16' if a.dtype == 'bf16' else ('bf16' if a.dtype == 'f16' else None)
@@ -726,6 +818,10 @@ def run_eps_greedy(a, job):
             'config': {'workload': 'EDM ImageNet-64 (ADM 295.9M) eps-greedy search iteration, imagenet scorer, sigma step 5/18',
                        'candidates_total': n_total, 'candidates_per_gpu': it.nl, 'rows_per_step_total': 2 * n_total,
                        'scorer': a.scorer, 'scorer_dtype': str(scorer_dtype(dtype)).split('.')[-1] if a.scorer == 'imagenet' else 'f64',
+                       'denoiser_dtype': a.dtype,
+                       # every forward of the timed region was a replayed HIP graph (a refused capture is an ERROR under bench.py: DTS_GRAPHS_STRICT)
+                       'graph_replay': bool(net._graphs.enabled and graph_replays > 0), 'graph_replays_in_timed_region': graph_replays,
+                       'reuse_winner': 'n/a: a bench step evaluates all N candidates; generate_image_grid (e2e_evals_per_s) reuses the winner row in the 16-bit modes',
                        'parallelism': f'candidates sharded x{world}, 1 all-gather of rewards per step'},
             'rccl_ranks': world if (world > 1 and job.backend == 'nccl') else (0 if world > 1 else 1),
             'dist_backend': job.backend, 'weak_value': None if weak is None else round(weak, 2),
@@ -762,7 +858,7 @@ def oracle_rejection32_step(n_total, seed=0):
         reps += 1
     dt = time.perf_counter() - t0
     return {'value': round(2 * n_total * reps / dt, 2), 'unit': 'candidate U-Net steps/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'seconds': round(dt, 2), 'sample': f'{reps} Heun steps of the same workload ({n_total} trajectories = {2 * n_total} DDPM++-32 denoiser rows each, '
+            'seconds': round(dt, 2), 'cpu_model': cpu_model(), 'sample': f'{reps} Heun steps of the same workload ({n_total} trajectories = {2 * n_total} DDPM++-32 denoiser rows each, '
                                                f'+ brightness score), fp32 torch-CPU oracle'}, float(sc.max())
 
 
@@ -776,7 +872,7 @@ def rejection32_record(a, job, steps=None, warmup=None, cpu=True):
     from diffusion_tts_amd.parallel import CandidateShards
     from diffusion_tts_amd.sampler import _Loop
     from diffusion_tts_amd.scorers import BrightnessScorer
-    dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[a.dtype]
+    dtype = torch_dtype(a.dtype)
     world, rank, dev = job.world, job.rank, job.dev
     steps = a.steps if steps is None else steps
     warmup = a.warmup if warmup is None else warmup
@@ -841,7 +937,7 @@ def mcts_record(a, job, S, steps, warmup, built=None):
     import numpy as np
     import torch
     from diffusion_tts_amd.sampler import SamplingMethod, generate_image_grid
-    dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[a.dtype]
+    dtype = torch_dtype(a.dtype)
     net, scorer = built if built is not None else build_adm(job, dtype, scorer_name=a.scorer)[:2]
     lat = torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(3))
     lab = torch.eye(1000)[torch.tensor([5])]
@@ -887,6 +983,7 @@ def run_mcts(a, job):
 
 
 def main():
+    os.environ.setdefault('DTS_GRAPHS_STRICT', '1')      # a refused HIP-graph capture must fail the measurement, not fall back to eager launches
     a = parse()
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(a.gpus))          # before any GPU / HIP call in this process

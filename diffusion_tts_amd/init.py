@@ -143,6 +143,20 @@ def classifier_state_dict(cfg: ClassifierConfig, seed: int = 1):
     return sd
 
 
+HEAD_SCALE_DECIDABLE = 20.0
+
+
+def scale_classifier_head(sd, head_scale: float = HEAD_SCALE_DECIDABLE):
+    """The second, documented classifier fixture: the same constructor draws and seeds, with the output head
+    (AttentionPool2d.c_proj, edm/unet.py:61-69) multiplied by `head_scale`, so that the 1000 logits of the random-init classifier have
+    a standard deviation of ~3.4 (0.17 x 20) like a trained classifier's instead of 0.17, and the target-class probability of two
+    candidates differs by per cent instead of by 1e-4 relative.  Used alike by the oracle and the build (it is a state dict)."""
+    out = OrderedDict(sd)
+    for k in ('out.2.c_proj.weight', 'out.2.c_proj.bias'):
+        out[k] = sd[k] * head_scale
+    return out
+
+
 def refill_degenerate(sd, seed: int, threshold: float = 1e-4):
     """SURVEY.md 8(d) weight rule.  Parameters with max|.| < threshold are re-drawn, in dict order, from
     torch.Generator().manual_seed(seed + 1): tensors with >= 2 dims as U(-b, b), b = sqrt(3 / fan_in),

@@ -11,7 +11,8 @@ Arguments (verbatim from the reference):
 Additions (the reference hard-codes a checkpoint URL, main.py:157-158; there is no network here):
     --network   : 'random:adm_imagenet64[:seed]' (default), 'random:ddpmpp_cifar10[:seed]', the local path of an NVIDIA EDM
                   network pickle (*.pkl, read without executing its embedded source), or a .pt bundle
-    --dtype     : bf16 (default) | f16 | f32 (parity mode)
+    --dtype     : bf16 (default) | f16 | f32 (parity mode, f32 matrix instruction) | f16x3 (split precision on the 16-bit matrix cores:
+                  near-f32 rewards, the reference's selections, ~2.5x the f32 mode's speed)
     --seeds LIST --outdir DIR [--subdirs] [--class N]: bulk mode (flags of the reference's edm/generate.py): one search per
                   seed, <outdir>/<seed:06d>.png; with torch.distributed.run the SEEDS are split over the ranks (no collective)
 Multi-GPU: launch with `python -m torch.distributed.run --nproc-per-node N main.py ...`; the N candidates of every
@@ -29,15 +30,15 @@ if ROOT not in sys.path:
 
 
 def get_scorer(backend, scorer_name, device, compute_dtype=None):
-    """main.py:60-71 of the reference.  compute_dtype: the search's --dtype; the ImageNet classifier runs in float32 for the parity
-    mode and in float16 otherwise (also beside a bfloat16 denoiser: scorers.ImageNetScorer)."""
+    """main.py:60-71 of the reference.  compute_dtype: the search's --dtype; the ImageNet classifier runs in the search's own mode for the two parity
+    modes (float32, f16x3) and in float16 otherwise (also beside a bfloat16 denoiser: scorers.ImageNetScorer)."""
     from diffusion_tts_amd import scorers as S
     if scorer_name == 'brightness':
         return S.BrightnessScorer(dtype=torch.float32)
     if scorer_name == 'compressibility':                               # sd/scorers.py:79 normalises by 150000 bytes, edm/scorers.py:177 by 3000
         return S.CompressibilityScorer(dtype=torch.float32, max_size=150000 if backend == 'sd' else 3000)
     if scorer_name == 'imagenet' and backend == 'edm':
-        return S.ImageNetScorer(dtype=torch.float32, device=device, compute_dtype=torch.float32 if compute_dtype == torch.float32 else torch.float16)
+        return S.ImageNetScorer(dtype=torch.float32, device=device, compute_dtype=compute_dtype if compute_dtype in (torch.float32, 'f16x3') else torch.float16)
     if scorer_name == 'clip' and backend == 'sd':
         return S.CLIPScorer(dtype=torch.float32, device=device)        # local HF cache only; raises with instructions otherwise
     raise ValueError(f"Unknown or invalid scorer '{scorer_name}' for backend '{backend}'")
@@ -127,7 +128,7 @@ def main(argv=None):
     parser.add_argument('--seed', type=int, default=0, help='Random seed')
     parser.add_argument('--device', type=str, default='cuda', help='Device')
     parser.add_argument('--network', type=str, default='random:adm_imagenet64', help='EDM network spec (see module docstring)')
-    parser.add_argument('--dtype', type=str, default='bf16', choices=['bf16', 'f16', 'f32'], help='activation dtype')
+    parser.add_argument('--dtype', type=str, default='bf16', choices=['bf16', 'f16', 'f32', 'f16x3'], help='compute mode (see the module docstring)')
     parser.add_argument('--vae', type=str, default='hip', choices=['hip', 'diffusers'],
                         help="SD backend: 'hip' = this build's VAE decoder (an error if its safetensors cannot be read), 'diffusers' = the stock module")
     parser.add_argument('--seeds', type=str, default=None, help='bulk mode: seeds, e.g. 0-63 or 1,2,5-10 (one image per seed)')
@@ -157,7 +158,8 @@ def main(argv=None):
     torch.cuda.set_device(device)
 
     from diffusion_tts_amd.sampler import SamplingMethod, generate_image_grid, load_network
-    dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[args.dtype]
+    from diffusion_tts_amd.ops import F16X3
+    dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32, 'f16x3': F16X3}[args.dtype]
     scorer = get_scorer('edm', args.scorer, device, compute_dtype=dtype)
     net = load_network(args.network, device=device, dtype=dtype)
     if args.seeds is not None:                                                        # bulk mode: seeds sharded over the ranks

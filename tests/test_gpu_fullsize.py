@@ -22,7 +22,11 @@ def adm():
     return cfg, sd
 
 
-@pytest.mark.parametrize('dtype,tol', [(torch.float32, 3e-4), (torch.bfloat16, 8e-2)])
+X3 = 'f16x3'          # ops.F16X3: split precision on the 16-bit matrix cores; held to the f32 parity mode's tolerances
+
+
+# tolerances = 3 x the measured error (r04: f32 2.3e-7, f16x3 2.1e-7, f16 1.9e-4, bf16 1.5e-3 of max|D|; round 3 asserted 3e-4 / 8e-2)
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 7e-7), (X3, 7e-7), (torch.float16, 6e-4), (torch.bfloat16, 4.5e-3)])
 def test_adm64_forward_matches_oracle(adm, manifest, dtype, tol):
     from diffusion_tts_amd.networks import EDMPrecond
     cfg, sd = adm
@@ -36,6 +40,7 @@ def test_adm64_forward_matches_oracle(adm, manifest, dtype, tol):
     want = oracle_net(cfg, sd)(x, sigma, lab)
     got = EDMPrecond(cfg, sd, device=DEV, dtype=dtype)(x, sigma, lab).cpu()
     err = (got - want).abs().max().item() / max(1.0, want.abs().max().item())
+    print(f'ADM-64 forward vs oracle, {dtype}: max err / max|D| = {err:.3e}')
     assert err < tol, err
 
 
@@ -157,12 +162,19 @@ def test_baseline_config3_adm64_eps_greedy_imagenet_scorer_reduced(adm):
                                sampling_method=sm.SamplingMethod.EPS_GREEDY, sampling_params=dict(scorer=scorer, **params),
                                scale_fn=seed0_scale, compute_dtype=torch.float32, verbose=False, **kw)
     assert h['net_rows'] == onet.evals
-    same, _ = check_decisions(o['rewards'], o['selected'], h['selected'], 'config 3 eps-greedy (reduced)')
-    for k_, (ro, rh) in enumerate(zip(o['rewards'], h['rewards'])):
-        if same or k_ == 0:
-            assert (ro - rh).abs().max().item() < 5e-5
-    if same:
-        assert (o['x'] - h['x'].cpu()).abs().max().item() < 1e-3
+    # every decision is checked, unconditionally: the states are identical as long as the picks were, so the reward deviation of an
+    # iteration IS the f32 mode's noise there (measured ~1e-8), and with N = 4 the top-2 gaps of this seed are far above it
+    assert len(o['rewards']) == len(h['rewards']) == len(o['selected']) == len(h['selected'])
+    for k_, (ro, rh, so, sh) in enumerate(zip(o['rewards'], h['rewards'], o['selected'], h['selected'])):
+        err = (ro - rh.cpu()).abs().max().item()
+        top = torch.sort(ro.reshape(ro.shape[0], -1), dim=0, descending=True).values
+        gap = float((top[0] - top[1]).min())
+        print(f'config 3 reduced, decision {k_}: reward err {err:.2e}, oracle top-2 gap {gap:.2e}')
+        assert err < 5e-5, (k_, err)
+        # gap == 0: identical candidate rows (a dead sigma-step) give bit-identical rewards on both sides: first-max rule
+        assert gap == 0.0 or gap > 4 * err, f'decision {k_}: top-2 gap {gap:.2e} is not above the fp32 noise {err:.2e} -- pick another seed'
+        assert torch.equal(so.reshape(-1), sh.cpu().reshape(-1)), (k_, so, sh)
+    assert (o['x'] - h['x'].cpu()).abs().max().item() < 1e-3
 
 
 def _adm_and_scorers(adm, dtype, scorer_dtype=None):
@@ -175,7 +187,7 @@ def _adm_and_scorers(adm, dtype, scorer_dtype=None):
     csd, _ = dinit.refill_degenerate(dinit.classifier_state_dict(ccfg, 1), 1)
     net = EDMPrecond(cfg, sd, device=DEV, dtype=dtype)
     if scorer_dtype is None:
-        scorer_dtype = torch.float16 if dtype == torch.bfloat16 else dtype
+        scorer_dtype = torch.float16 if dtype == torch.bfloat16 else dtype         # (f16x3 scores in f16x3)
     scorer = S.ImageNetScorer(weights=csd, cfg=ccfg, device=DEV, compute_dtype=scorer_dtype)
     return net, scorer, oracle_net(cfg, sd), oscore.ImageNetOracle(oracle_cls_cfg(ccfg), csd)
 
@@ -254,12 +266,19 @@ def test_config3_whole_search_index_agreement_teacher_forced(adm):
     class _Job:
         dev = torch.device(DEV)
     nets = {}
-    for name, dt in (('f32', torch.float32), ('f16', torch.float16), ('bf16', torch.bfloat16)):
+    for name, dt in (('f32', torch.float32), ('f16x3', X3), ('f16', torch.float16), ('bf16', torch.bfloat16)):
         net, scorer, _, _ = _adm_and_scorers(adm, dt)
         nets[name] = (net, scorer)
     rec = bench.teacher_forced_agreement(_Job(), nets, n=64, K=4, num_steps=18)
     print('whole-search index agreement:', rec)
     assert rec['iterations'] == 72
+    # split precision: its rewards sit at the distance from the f32 mode's that two f32 summation orders have from each other (measured
+    # 1.1e-8, the f32 mode itself is 7e-9 from the CPU oracle), against a median top-2 gap of 1.3e-7: most iterations are decidable, every
+    # decidable one agrees, and the picks agree on all but near-ties below that noise (measured 71/72, regret 1.2e-10)
+    r3 = rec['f16x3']
+    a3, n3 = map(int, r3['agree_decidable'].split('/'))
+    assert n3 >= 36 and a3 == n3, r3
+    assert int(r3['agree'].split('/')[0]) >= 68 and r3['max_reward_dev_vs_f32'] < 5e-8 and r3['max_regret'] <= 1e-8, r3
     for name in ('f16', 'bf16'):
         r = rec[name]
         a_, n_ = map(int, r['agree_decidable'].split('/'))
@@ -268,6 +287,33 @@ def test_config3_whole_search_index_agreement_teacher_forced(adm):
         assert r['max_regret'] <= 1e-6, (name, r)
         assert r['max_reward_dev_vs_f32'] < 1e-5, (name, r)
         assert int(r['agree'].split('/')[0]) >= 0.75 * 72, (name, r)
+
+
+def test_config3_free_running_search_split_precision_equals_f32_and_16bit_is_reported(adm):
+    """BASELINE.json configs[2] END TO END and free-running (generate_image_grid, eps-greedy N = 64 K = 4, 18 sigma steps, 8995 denoiser
+    rows), per compute mode from the same host RNG.  The split-precision mode must make the f32 parity mode's 72 selections and end within
+    1e-3 of its final image (north_star: selected indices bit-exact, final images within 1e-3 abs; measured 72/72 and 1.4e-6).  The 16-bit
+    throughput modes pick another near-tied candidate after ~10 decisions (the f32 top-2 gaps are ~1e-7, their reward noise 3e-7 .. 5e-7)
+    and from there follow ANOTHER trajectory: their final image is a different sample (measured max |dx| ~4), which is stated, not hidden:
+    asserted for them is what the search is for -- the final reward is as good as the f32 search's (within 2 %)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    class _Job:
+        dev = torch.device(DEV)
+    nets = {}
+    for name, dt in (('f32', torch.float32), ('f16x3', X3), ('f16', torch.float16), ('bf16', torch.bfloat16)):
+        net, scorer, _, _ = _adm_and_scorers(adm, dt)
+        nets[name] = (net, scorer)
+    rec = bench.free_running_vs_f32(_Job(), nets)
+    print('free-running config-3 searches vs the f32 parity mode:', rec)
+    r3 = rec['f16x3']
+    assert r3['same_selections'] == '72/72' and r3['max_abs_x_final_vs_f32'] < 1e-3, r3
+    for name in ('f16', 'bf16'):
+        r = rec[name]
+        assert np.isfinite(r['max_abs_x_final_vs_f32']) and abs(r['final_score'] / rec['f32_final_score'] - 1) < 0.02, (name, r)
 
 
 def test_config5_mcts_full_size_matches_oracle(adm):

@@ -154,7 +154,9 @@ def test_search_throughput_modes_stay_close(pkg, golden, manifest, dtype):
     assert res['net_rows'] == meta['net_rows']
     ref_x = T(golden['naive_adm_last_D']).double()
     err = (res['x'].cpu() - ref_x).abs().max().item()
-    assert np.isfinite(err) and err < (0.05 if dtype == torch.float16 else 0.25), err
+    print(f'naive sampler, tiny ADM, {dtype}: max |x_final - reference| = {err:.3e}')
+    # measured (r04): 7.1e-3 (f16), 4.6e-2 (bf16); bound = 2 x that (round 3 asserted 0.05 / 0.25)
+    assert np.isfinite(err) and err < (1.5e-2 if dtype == torch.float16 else 1e-1), err
     meta, res = run_case(pkg, golden, manifest, 'epsgreedy_adm_bright', dtype)
     # free-running search (a differing pick changes everything after it), brightness rewards: every selection is compared with the
     # reference's as long as the two searches have made the same picks so far (same state: the reward deviation measured there is the

@@ -2,11 +2,15 @@
 # copies the summaries of tools/final_run.sh (gpurun_out/final_*) into profiles/ under the round's names:  tools/collect_profiles.sh r03
 set -e
 cd "$(dirname "$0")/.."
-RD=${1:-r03}; O=gpurun_out
+RD=${1:-r04}; O=gpurun_out
 cp "$(ls -t $O/final_prof/*/*kernel_stats.csv | head -1)" profiles/${RD}_bench_kernel_stats.csv
 cp "$(ls -t $O/final_prof_c8/*/*kernel_stats.csv | head -1)" profiles/${RD}_c8_kernel_stats.csv
 grep "^{" $O/final_bench.json > profiles/${RD}_bench.json
-cp $O/final_hbm_traffic_pmc.json profiles/${RD}_hbm_traffic_pmc.json
+python - $O/final_hbm_traffic_pmc.json profiles/${RD}_hbm_traffic_pmc.json "$(git rev-parse --short HEAD)" <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1])); d['collected_at_commit'] = sys.argv[3]      # the tree the counters were collected from (bench.py quotes it)
+json.dump(d, open(sys.argv[2], 'w'))
+PY
 cp $O/final_conv_sequence.json profiles/${RD}_conv_sequence.json
 { echo "# per conv layer shape of one search iteration (bench.py --conv-sequence): PMC HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes) next to the algorithmic bytes"
   echo "# (every input / weight / residual element read once, every output element written once).  x 'launches per step'; time and TFLOP/s from the in-process dispatch events."

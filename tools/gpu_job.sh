@@ -2,5 +2,8 @@
 # scratch GPU job of the moment (one gpurun call): edit, run, read gpurun_out/job_*.  Committed form = the last job run.
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
-timeout -k 10 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_search.py -m gpu -q --timeout 300 -s -k "split_precision or conv2d or search_parity or denoiser_forward or classifier_and" > $O/job_x3.log 2>&1 || { grep -v "^split precision" $O/job_x3.log | tail -40; grep "^split precision" $O/job_x3.log; exit 1; }
-grep "^split precision" $O/job_x3.log; tail -2 $O/job_x3.log
+timeout -k 10 1000 python -m pytest tests/test_gpu_fullsize.py -m gpu -q --timeout 900 -s -k reduced > $O/job_suite.log 2>&1 || { grep -a -v "^split precision" $O/job_suite.log | tail -40; exit 1; }
+grep -a "naive sampler, tiny\|config 3 reduced\|decidable selections" $O/job_suite.log; tail -1 $O/job_suite.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python bench.py --steps 10 --warmup 2 > $O/job_bench.json 2> $O/job_bench.err || { tail -20 $O/job_bench.err; exit 1; }
+grep -a "bench +" $O/job_bench.err | grep -v " conv (" | cut -c1-400 | tail -30
