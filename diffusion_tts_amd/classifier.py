@@ -35,6 +35,7 @@ class EncoderUNetModel:
             raise RuntimeError('EncoderUNetModel (HIP) needs a GPU: there is no CPU fallback in this package')
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
         self.act_dtype = ops.act_dtype(dtype)            # float32 activations in the split-precision mode (ops.F16X3)
+        self.x3 = dtype == ops.F16X3
         from .graphs import GraphCache
         self._graphs = GraphCache(self._device_forward)
         f = lambda t: t.detach().to(self.device, torch.float32).contiguous()
@@ -85,19 +86,19 @@ class EncoderUNetModel:
 
     def _res(self, L: ClsLayer, x, emb_all):
         P = self.params[L.prefix]
-        h = ops.group_norm(x, 32, 1e-5, P.g0, P.b0, silu=True, pool=L.down)
+        h = ops.group_norm(x, 32, 1e-5, P.g0, P.b0, silu=True, pool=L.down, split_out=self.x3)
         if L.down:
             x = ops.resample2x(x, up=False)
         h = ops.conv2d(h, P.w0, P.cb0, gn_stats=True)
         ss = emb_all[:, P.off:P.off + 2 * L.cout]
-        h = ops.group_norm(h, 32, 1e-5, P.g1, P.b1, scale_shift=ss, silu=True)
+        h = ops.group_norm(h, 32, 1e-5, P.g1, P.b1, scale_shift=ss, silu=True, split_out=self.x3)
         sk = x if P.sw is None else ops.conv2d(x, P.sw, P.sb)
         return ops.conv2d(h, P.w1, P.cb1, residual=sk, gn_stats=True)
 
     def _attn(self, L: ClsLayer, x):
         P = self.params[L.prefix]
         n, hh, ww, c = x.shape
-        hn = ops.group_norm(x, 32, 1e-5, P.g, P.b, silu=False)
+        hn = ops.group_norm(x, 32, 1e-5, P.g, P.b, silu=False, split_out=self.x3)
         qkv = ops.conv2d(hn, P.wqkv, P.bqkv)
         a = ops.attention(qkv.view(n, hh * ww, 3 * c), P.heads, 1.0 / math.sqrt(c // P.heads))
         return ops.conv2d(a.view(n, hh, ww, c), P.wproj, P.bproj, residual=x, gn_stats=True)

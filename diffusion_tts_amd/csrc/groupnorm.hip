@@ -171,13 +171,32 @@ __global__ __launch_bounds__(256) void gn_coef_strips_kernel(const float* __rest
 template <typename T> __device__ __forceinline__ float silu_t(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 template <> __device__ __forceinline__ float silu_t<float>(float x) { return silu_f(x); }
 
+// Split-precision output (dts.h DTS_F16X3, the arithmetic of split3_f16_kernel): 4 consecutive channels c0.. of one pixel row of C
+// channels go out as f16 hi | lo * 2^11 | hi at channel offsets c0, C + c0, 2C + c0 of the 3C-wide row `orow` -- what the consuming
+// convolution reads, so the f32 tensor in between (one write + one read) and the separate split pass disappear.
+__device__ __forceinline__ void store_split4(f16_t* orow, int C, int c0, const float* f) {
+  float hi[4], lo[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float h = f16_bits_to_f32(f32_to_f16_bits(f[e]));
+    if (fabsf(h) < 6.103515625e-05f) h = 0.f;            // the matrix cores flush f16 subnormals: the whole value goes to the lo plane
+    hi[e] = h;
+    lo[e] = (f[e] - h) * 2048.0f;
+  }
+  const uint2 h2 = make_uint2(pack2_f16(hi[0], hi[1]), pack2_f16(hi[2], hi[3])), l2 = make_uint2(pack2_f16(lo[0], lo[1]), pack2_f16(lo[2], lo[3]));
+  *reinterpret_cast<uint2*>(orow + c0) = h2;
+  *reinterpret_cast<uint2*>(orow + C + c0) = l2;
+  *reinterpret_cast<uint2*>(orow + 2 * C + c0) = h2;
+}
+
 // Apply pass, row form: a block works on a pixel range of ONE sample and every thread keeps ONE 16-byte channel chunk, so
 // its (a,b) coefficients are loaded once and the loop body is load -> fma/SiLU -> store with no index arithmetic (the
 // grid-stride form below spends more VALU cycles on 64-bit div/mod per element than on the SiLU).  blockDim = k * nchunk.
-template <typename T>
+template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const T* __restrict__ x1, int c1, const T* __restrict__ x2, int c2,
                                                              const float* __restrict__ coef, T* __restrict__ out, int hw, int ppb,
                                                              int silu) {
+  static_assert(!SPLIT || sizeof(T) == 4, "split-precision output is the f32 mode's");
   constexpr int EPV = ET<T>::EPV;
   const int C = c1 + c2, nchunk = C / EPV;
   const int k = blockDim.x / nchunk;
@@ -192,6 +211,7 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const T* __restrict_
   const T* src; int cs;
   if (c0 < c1) { src = x1 + (size_t)n * hw * c1 + c0; cs = c1; } else { src = x2 + (size_t)n * hw * c2 + (c0 - c1); cs = c2; }
   T* dst = out + (size_t)n * hw * C + c0;
+  f16_t* const dst3 = reinterpret_cast<f16_t*>(out) + (size_t)n * hw * 3 * C;       // SPLIT: rows of 3C f16
   const int p_begin = blockIdx.x * ppb, p_end = min(hw, p_begin + ppb);
   int p = p_begin + pr;
   // two independent pixels per trip keep two loads in flight per thread
@@ -207,8 +227,13 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const T* __restrict_
       f0[e] = silu ? silu_t<T>(y0) : y0;
       f1[e] = silu ? silu_t<T>(y1) : y1;
     }
-    *reinterpret_cast<uint4*>(dst + (size_t)p * C) = pack16<T>(f0);
-    *reinterpret_cast<uint4*>(dst + (size_t)(p + k) * C) = pack16<T>(f1);
+    if constexpr (SPLIT) {
+      store_split4(dst3 + (size_t)p * 3 * C, C, c0, f0);
+      store_split4(dst3 + (size_t)(p + k) * 3 * C, C, c0, f1);
+    } else {
+      *reinterpret_cast<uint4*>(dst + (size_t)p * C) = pack16<T>(f0);
+      *reinterpret_cast<uint4*>(dst + (size_t)(p + k) * C) = pack16<T>(f1);
+    }
   }
   if (p < p_end) {
     const uint4 v0 = *reinterpret_cast<const uint4*>(src + (size_t)p * cs);
@@ -216,11 +241,12 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const T* __restrict_
     unpack16<T>(v0, f0);
 #pragma unroll
     for (int e = 0; e < EPV; ++e) { const float y0 = f0[e] * A[e] + B[e]; f0[e] = silu ? silu_t<T>(y0) : y0; }
-    *reinterpret_cast<uint4*>(dst + (size_t)p * C) = pack16<T>(f0);
+    if constexpr (SPLIT) store_split4(dst3 + (size_t)p * 3 * C, C, c0, f0);
+    else *reinterpret_cast<uint4*>(dst + (size_t)p * C) = pack16<T>(f0);
   }
 }
 
-template <typename T, bool POOL>
+template <typename T, bool POOL, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1, int c1, const T* __restrict__ x2, int c2,
                                                         const float* __restrict__ coef, T* __restrict__ out,
                                                         int n_total, int h, int w, int silu) {
@@ -264,7 +290,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1,
           for (int e = 0; e < EPV; ++e) { const float y = f[e] * A[e] + B[e]; r[e] += 0.25f * (silu ? silu_t<T>(y) : y); }
         }
     }
-    *reinterpret_cast<uint4*>(out + (((size_t)n * ho + yo) * wo + xo) * C + c0) = pack16<T>(r);
+    if constexpr (SPLIT) store_split4(reinterpret_cast<f16_t*>(out) + (((size_t)n * ho + yo) * wo + xo) * 3 * C, C, c0, r);
+    else *reinterpret_cast<uint4*>(out + (((size_t)n * ho + yo) * wo + xo) * C + c0) = pack16<T>(r);
   }
 }
 
@@ -448,8 +475,18 @@ extern "C" int dts_gn_coef_strips(const float* st1, int c1, const float* st2, in
   return DTS_OK;
 }
 
+static int gn_apply_impl(const void* x1, int c1, const void* x2, int c2, int dtype, const float* coef, void* out, int n, int h,
+                         int w, int silu, int pool, bool split, dts_stream s);
 extern "C" int dts_gn_apply(const void* x1, int c1, const void* x2, int c2, int dtype, const float* coef, void* out, int n, int h,
                             int w, int silu, int pool, dts_stream s) {
+  return gn_apply_impl(x1, c1, x2, c2, dtype, coef, out, n, h, w, silu, pool, false, s);
+}
+extern "C" int dts_gn_apply_x3(const float* x1, int c1, const float* x2, int c2, const float* coef, void* out, int n, int h,
+                               int w, int silu, int pool, dts_stream s) {
+  return gn_apply_impl(x1, c1, x2, c2, DTS_F32, coef, out, n, h, w, silu, pool, true, s);
+}
+static int gn_apply_impl(const void* x1, int c1, const void* x2, int c2, int dtype, const float* coef, void* out, int n, int h,
+                         int w, int silu, int pool, bool split, dts_stream s) {
   const int C = c1 + c2;
   DTS_CHECK_ARG(x1 && coef && out, "dts_gn_apply: null pointer");
   DTS_CHECK_ARG(c2 == 0 || x2, "dts_gn_apply: c2 without x2");
@@ -458,6 +495,23 @@ extern "C" int dts_gn_apply(const void* x1, int c1, const void* x2, int c2, int 
   DTS_CHECK_ARG(!pool || (h % 2 == 0 && w % 2 == 0), "dts_gn_apply: pool needs even h,w");
   hipStream_t st = to_stream(s);
   const long long total = (long long)n * (pool ? h / 2 : h) * (pool ? w / 2 : w) * (C / epv);
+  if (split) {                                           // f32 in, f16 split image out (dts.h dts_gn_apply_x3)
+    using T = float;
+    if (pool)
+      hipLaunchKernelGGL((gn_apply_kernel<T, true, true>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x1, c1, (const T*)x2,
+                         c2, coef, (T*)out, n, h, w, silu);
+    else if (C / epv <= 256 && n <= 65535) {
+      const int nchunk = C / epv, k = 256 / nchunk, hw = h * w;
+      long long ppb = ((long long)n * hw + 4095) / 4096;
+      ppb = ((ppb + 2 * k - 1) / (2 * k)) * (2 * k);
+      hipLaunchKernelGGL((gn_apply_rows_kernel<T, true>), dim3((unsigned)((hw + ppb - 1) / ppb), n), dim3(k * nchunk), 0, st, (const T*)x1, c1,
+                         (const T*)x2, c2, coef, (T*)out, hw, (int)ppb, silu);
+    } else
+      hipLaunchKernelGGL((gn_apply_kernel<T, false, true>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x1, c1, (const T*)x2,
+                         c2, coef, (T*)out, n, h, w, silu);
+    DTS_CHECK_LAUNCH("dts_gn_apply_x3");
+    return DTS_OK;
+  }
   DTS_DISPATCH_DTYPE(dtype, {
     if (pool)
       hipLaunchKernelGGL((gn_apply_kernel<T, true>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x1, c1, (const T*)x2,

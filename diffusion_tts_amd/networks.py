@@ -48,6 +48,7 @@ class EDMPrecond:
         self.device = torch.device(device)
         self.dtype = dtype                               # compute mode: float32 (parity) | bfloat16 | float16 | ops.F16X3 (split precision)
         self.act_dtype = ops.act_dtype(dtype)            # storage type of the activations
+        self.x3 = dtype == ops.F16X3                     # GroupNorm results that only feed a convolution leave as its split operand image
         self.img_resolution, self.img_channels, self.label_dim = cfg.img_resolution, cfg.img_channels, cfg.label_dim
         self.sigma_min, self.sigma_max, self.sigma_data = cfg.sigma_min, cfg.sigma_max, cfg.sigma_data
         self.use_fp16 = dtype == torch.float16
@@ -177,13 +178,13 @@ class EDMPrecond:
             coef = ops.gn_coefficients(x1, G(b.cin), self.eps, P.g0, P.b0, x2=x2)
             h = ops.conv2d(x1, P.w0, P.cb0, x2=x2, up=b.up, bias_nc=bnc, gn_stats=True, gn_coef=coef, gn_silu=True)
         else:
-            h = ops.group_norm(x1, G(b.cin), self.eps, P.g0, P.b0, x2=x2, silu=True, pool=b.down)
+            h = ops.group_norm(x1, G(b.cin), self.eps, P.g0, P.b0, x2=x2, silu=True, pool=b.down, split_out=self.x3)
             h = ops.conv2d(h, P.w0, P.cb0, up=b.up, bias_nc=bnc, gn_stats=True)
         fuse1 = self.fuse_gn and ops.conv_fuses_gn(h, P.w1)
         if fuse1:        # norm1 (+ adaptive scale/shift) + SiLU inside conv1 (networks.py:173-175)
             coef1 = ops.gn_coefficients(h, G(b.cout), self.eps, P.g1, P.b1, scale_shift=ss if self.adm else None)
         else:
-            h = ops.group_norm(h, G(b.cout), self.eps, P.g1, P.b1, scale_shift=ss if self.adm else None, silu=True)
+            h = ops.group_norm(h, G(b.cout), self.eps, P.g1, P.b1, scale_shift=ss if self.adm else None, silu=True, split_out=self.x3)
         if P.skip_w is not None:
             src1, src2 = (ops.resample2x(x1, up=False), None) if b.down else (x1, x2)
             sk = ops.conv2d(src1, P.skip_w, P.skip_b, x2=src2, up=b.up)
@@ -195,7 +196,7 @@ class EDMPrecond:
                        gn_coef=coef1 if fuse1 else None, gn_silu=True)
         if b.heads:
             n, hh, ww, c = x.shape
-            hn = ops.group_norm(x, G(c), self.eps, P.g2, P.b2, silu=False)
+            hn = ops.group_norm(x, G(c), self.eps, P.g2, P.b2, silu=False, split_out=self.x3)
             qkv = ops.conv2d(hn, P.wqkv, P.bqkv)
             a = ops.attention(qkv.view(n, hh * ww, 3 * c), b.heads, 1.0 / math.sqrt(c // b.heads))
             x = ops.conv2d(a.view(n, hh, ww, c), P.wproj, P.bproj, residual=x, out_scale=self.skip_scale, gn_stats=True)

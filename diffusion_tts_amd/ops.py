@@ -42,6 +42,18 @@ class X3Weight:
         return self.packed.numel()
 
 
+class SplitAct:
+    """An activation already in the split-precision operand form: `data` float16 [n,h,w,3*C] = hi | lo * 2^11 | hi (dts_split3_f16 /
+    dts_gn_apply_x3); `shape` is the logical NHWC shape.  Only convolutions with an X3Weight read it."""
+
+    def __init__(self, data, c):
+        self.data, self.shape = data, tuple(data.shape[:3]) + (c,)
+        self.device, self.dtype = data.device, torch.float32
+
+    def numel(self):
+        return self.data.numel() // 3
+
+
 def dt_code(dtype):
     try:
         return _DT[dtype]
@@ -179,12 +191,15 @@ def conv2d(x1, w, bias=None, *, x2=None, bias_nc=None, residual=None, up=False, 
     x3 = isinstance(w, X3Weight)
     if x3 and (x1.dtype != torch.float32 or gn_coef is not None):
         raise ValueError('conv2d: a split-precision weight takes float32 activations (and no fused input GroupNorm)')
+    if isinstance(x1, SplitAct) and (not x3 or x2 is not None):
+        raise ValueError('conv2d: a split activation feeds a split-precision weight, alone')
     if out is None:
         out = torch.empty((n, ho, wo, cout), dtype=x1.dtype, device=x1.device)
     a = L.ConvArgs()
+    dt_in = x1.dtype
     if x3:      # the conv reads the f16 split image hi | lo | hi of concat(x1, x2); epilogue operands and output stay float32
-        xs = split3_f16(x1, x2)
-        a.x1, a.c1, a.x2, a.c2 = _ptr(xs), 3 * (c1 + c2), None, 0
+        xs = x1.data if isinstance(x1, SplitAct) else split3_f16(x1, x2)
+        a.x1, a.c1, a.x2, a.c2 = _ptr(xs, 'x1', torch.float16), 3 * (c1 + c2), None, 0
         a.w, a.acc_scale = _ptr(w.packed, 'w', torch.float16), w.acc_scale
     else:
         a.x1, a.c1 = _ptr(x1, 'x1'), c1
@@ -257,10 +272,16 @@ def gn_coef(x1, groups, eps, gamma, beta, *, x2=None, scale_shift=None):
     return coef
 
 
-def gn_apply(x1, coef, *, x2=None, silu=True, pool=False):
+def gn_apply(x1, coef, *, x2=None, silu=True, pool=False, split_out=False):
+    """split_out (float32 inputs only): the result leaves as the f16 split image a split-precision convolution reads (SplitAct)."""
     n, h, w, c1 = x1.shape
     c2 = 0 if x2 is None else x2.shape[-1]
     ho, wo = (h // 2, w // 2) if pool else (h, w)
+    if split_out:
+        out = torch.empty((n, ho, wo, 3 * (c1 + c2)), dtype=torch.float16, device=x1.device)
+        _call('dts_gn_apply_x3', _ptr(x1, 'x1', torch.float32), c1, _ptr(x2, 'x2', torch.float32), c2, _ptr(coef, 'coef', torch.float32),
+              _ptr(out), n, h, w, int(silu), int(pool))
+        return SplitAct(out, c1 + c2)
     out = torch.empty((n, ho, wo, c1 + c2), dtype=x1.dtype, device=x1.device)
     _call('dts_gn_apply', _ptr(x1, 'x1'), c1, _ptr(x2, 'x2', x1.dtype), c2, dt_code(x1.dtype),
           _ptr(coef, 'coef', torch.float32), _ptr(out), n, h, w, int(silu), int(pool))
@@ -294,8 +315,9 @@ def gn_coefficients(x1, groups, eps, gamma, beta, *, x2=None, scale_shift=None):
     return coef if coef is not None else gn_coef(x1, groups, eps, gamma, beta, x2=x2, scale_shift=scale_shift)
 
 
-def group_norm(x1, groups, eps, gamma, beta, *, x2=None, scale_shift=None, silu=True, pool=False, path=None):
-    """GroupNorm [+ (1+scale), shift] [+ SiLU] [+ 2x2 average pool].  path: None = auto, 'fused' | 'split' (tests)."""
+def group_norm(x1, groups, eps, gamma, beta, *, x2=None, scale_shift=None, silu=True, pool=False, path=None, split_out=False):
+    """GroupNorm [+ (1+scale), shift] [+ SiLU] [+ 2x2 average pool].  path: None = auto, 'fused' | 'split' (tests).
+    split_out: float32 in, SplitAct out (the operand form of a split-precision convolution)."""
     n, h, w, c1 = x1.shape
     c2 = 0 if x2 is None else x2.shape[-1]
     cg = (c1 + c2) // groups
@@ -303,11 +325,11 @@ def group_norm(x1, groups, eps, gamma, beta, *, x2=None, scale_shift=None, silu=
     if path in (None, 'strips'):
         coef = _coef_from_strips(x1, x2, groups, eps, gamma, beta, scale_shift)
         if coef is not None:
-            return gn_apply(x1, coef, x2=x2, silu=silu, pool=pool)
+            return gn_apply(x1, coef, x2=x2, silu=silu, pool=pool, split_out=split_out)
     if path == 'strips':
         raise ValueError('strip statistics are not attached to the input(s)')
     if path is None:
-        path = 'fused' if (fused_ok and h * w <= GN_FUSED_MAX_HW) else 'split'
+        path = 'fused' if (fused_ok and h * w <= GN_FUSED_MAX_HW and not split_out) else 'split'
     if path == 'fused':
         if not fused_ok:
             raise ValueError('fused GroupNorm needs pool=False and an even number (<= 64) of channels per group')
@@ -316,7 +338,8 @@ def group_norm(x1, groups, eps, gamma, beta, *, x2=None, scale_shift=None, silu=
         _call('dts_gn_fused', _ptr(x1, 'x1'), c1, _ptr(x2, 'x2', x1.dtype), c2, dt_code(x1.dtype), n, h * w, groups, float(eps),
               _ptr(gamma, 'gamma', torch.float32), _ptr(beta, 'beta', torch.float32), ss_ptr, ss_ld, _ptr(out), int(silu))
         return out
-    return gn_apply(x1, gn_coef(x1, groups, eps, gamma, beta, x2=x2, scale_shift=scale_shift), x2=x2, silu=silu, pool=pool)
+    return gn_apply(x1, gn_coef(x1, groups, eps, gamma, beta, x2=x2, scale_shift=scale_shift), x2=x2, silu=silu, pool=pool,
+                    split_out=split_out)
 
 
 def resample2x(x, up):

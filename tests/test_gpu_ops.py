@@ -161,6 +161,42 @@ def test_conv2d_split_precision(ops, case):
         assert torch.allclose(out._gn_stats, out32._gn_stats, rtol=1e-4, atol=1e-4 * max(1.0, scale) ** 2)
 
 
+@pytest.mark.parametrize('variant', ['plain', 'concat_ss', 'pool', 'wide'])
+def test_group_norm_split_precision_output(ops, variant):
+    """group_norm(..., split_out=True) (dts_gn_apply_x3): the normalised tensor leaves as the f16 split image hi | lo * 2^11 | hi -- bit for
+    bit what dts_split3_f16 makes of the f32 result of the plain pass -- and a split-precision conv reads it directly."""
+    gen = g(91)
+    n, h, w, c1, c2 = 3, 16, 16, 128, 0
+    if variant == 'concat_ss':
+        c1, c2 = 128, 64
+    if variant == 'wide':
+        n, h, w, c1 = 1, 8, 8, 1536                     # more than 256 chunks per row: the grid-stride kernel
+    C_ = c1 + c2
+    x1 = to_nhwc(ops, torch.randn(n, c1, h, w, generator=gen) * 2 + 0.5, torch.float32)
+    x2 = to_nhwc(ops, torch.randn(n, c2, h, w, generator=gen), torch.float32) if c2 else None
+    gamma, beta = torch.randn(C_, generator=gen).to(DEV), torch.randn(C_, generator=gen).to(DEV)
+    ss = (torch.randn(n, 2 * C_, generator=gen) * 0.3).to(DEV) if variant == 'concat_ss' else None
+    kw = dict(x2=x2, scale_shift=ss, silu=True, pool=variant == 'pool')
+    plain = ops.group_norm(x1, 32, 1e-5, gamma, beta, **kw)
+    sp = ops.group_norm(x1, 32, 1e-5, gamma, beta, split_out=True, **kw)
+    assert isinstance(sp, ops.SplitAct) and tuple(sp.shape) == tuple(plain.shape) and sp.data.dtype == torch.float16
+    ref3 = ops.split3_f16(plain)
+    ndiff = int((sp.data != ref3).sum())
+    rec_a = sp.data[..., :C_].float() + sp.data[..., C_:2 * C_].float() / 2048.0
+    print(f'gn split {variant}: {ndiff} of {ref3.numel()} f16 values differ from split3(plain); max |reconstructed - plain| = {float((rec_a - plain).abs().max()):.3e}')
+    if variant in ('plain', 'concat_ss'):                 # the row kernel: the same f32 values, so the same split image bit for bit
+        assert ndiff == 0
+    else:                                                 # the grid-stride kernel's two instantiations contract their FMAs differently: <= 1 f32 ulp apart
+        assert ndiff < 0.05 * ref3.numel() and bool(((rec_a - plain).abs() <= 2.4e-7 * plain.abs().clamp(min=1.0)).all())
+    # hi + lo * 2^-11 reproduces the f32 value to ~2^-22, and a split-precision conv takes the image as is
+    hi, lo = sp.data[..., :C_].float(), sp.data[..., C_:2 * C_].float()
+    assert torch.equal(sp.data[..., 2 * C_:], sp.data[..., :C_])
+    assert float((hi + lo / 2048.0 - plain).abs().max()) < 4e-7 * max(1.0, float(plain.abs().max()))
+    wt = torch.randn(64, C_, 1, 1, generator=gen) / math.sqrt(C_)
+    w3 = ops.pack_conv_weight(wt.to(DEV), ops.F16X3)
+    assert float((ops.conv2d(sp, w3) - ops.conv2d(plain, w3)).abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_conv2d_big_tiles(ops, dtype):
     """cout % 128 == 0 and >= 32768 pixels selects the 128x128 block tile."""
@@ -322,7 +358,7 @@ def test_ping_pong_conv_kernel_on_every_kind_of_shape(ops, dtype, n, res, c1, c2
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('variant', ['ping_pong', 'ring3'])
+@pytest.mark.parametrize('variant', ['ping_pong', 'ring3', 'ring4'])
 def test_conv_kernels_with_hand_counted_waits_repeat_bit_for_bit(ops, dtype, variant):
     """Race screen inside the suite (was tools/pp_stress.py): the kernels whose LDS-DMA loads are awaited by hand-counted `vmcnt` --
     conv_pp_kernel (forced on every eligible shape) and conv_igemm_kernel with its 3-deep ring -- launched 12 times per shape with the
@@ -335,10 +371,10 @@ def test_conv_kernels_with_hand_counted_waits_repeat_bit_for_bit(ops, dtype, var
         (8, 64, 192, 0, 192, 3, True), (8, 32, 384, 384, 384, 3, False), (16, 16, 576, 0, 576, 3, True), (8, 16, 576, 768, 576, 3, False),
         (8, 32, 256, 0, 256, 3, False), (8, 64, 128, 0, 128, 3, False), (8, 16, 1152, 0, 576, 3, False), (16, 32, 192, 0, 384, 3, False),
     ]
-    if variant == 'ring3':   # the 4-wave kernel's small-grid launches: 8x8 level (split-K), 1x1 layers, 16x16 level
+    if variant in ('ring3', 'ring4'):   # the 4-wave kernel's small-grid launches (ring4: the 4-deep ring of the DTS_CONV_STAGES A/B knob, 4 waves forced): 8x8 level (split-K), 1x1 layers, 16x16 level
         shapes = [(8, 8, 768, 0, 768, 3, True), (8, 8, 768, 768, 768, 3, False), (8, 8, 768, 0, 2304, 1, False), (8, 16, 576, 0, 576, 1, True),
                   (8, 16, 576, 0, 1728, 1, False), (16, 8, 512, 0, 512, 3, True), (8, 16, 576, 0, 576, 3, True), (2, 32, 384, 0, 1152, 1, False)]
-    knob, val = ('conv_variant', 1) if variant == 'ping_pong' else ('conv_stages', 3)
+    knob, val = ('conv_variant', 1) if variant == 'ping_pong' else ('conv_stages', 3 if variant == 'ring3' else 4)
     trash = torch.empty(32 << 20, device=DEV, dtype=torch.float32)
     for (n, res, c1, c2, cout, ks, use_res) in shapes:
         x1 = torch.randn(n, res, res, c1, device=DEV).to(dtype)
@@ -348,6 +384,8 @@ def test_conv_kernels_with_hand_counted_waits_repeat_bit_for_bit(ops, dtype, var
         b = torch.randn(cout, device=DEV)
         r = torch.randn(n, res, res, cout, device=DEV).to(dtype) if use_res else None
         _lib.set_tuning(knob, val)
+        if variant == 'ring4':
+            _lib.set_tuning('conv_waves', 4)          # the 8-wave form has no 4-deep ring
         try:
             if variant == 'ping_pong':
                 assert ops.conv_kernel(x1, w, x2=x2, residual=r) in (4, 6)
@@ -367,6 +405,8 @@ def test_conv_kernels_with_hand_counted_waits_repeat_bit_for_bit(ops, dtype, var
                     assert st is None or torch.equal(st, first_st), (variant, n, res, c1, c2, cout, ks, rep)
         finally:
             _lib.set_tuning(knob, -1)
+            if variant == 'ring4':
+                _lib.set_tuning('conv_waves', -1)
         ref = ops.conv2d(x1.float(), w.float(), b, x2=None if x2 is None else x2.float(), residual=None if r is None else r.float(),
                          out_scale=0.9)
         ulp = float(ref.abs().max()) * (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11)

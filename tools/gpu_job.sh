@@ -2,8 +2,9 @@
 # scratch GPU job of the moment (one gpurun call): edit, run, read gpurun_out/job_*.  Committed form = the last job run.
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
-timeout -k 10 1000 python -m pytest tests/test_gpu_fullsize.py -m gpu -q --timeout 900 -s -k reduced > $O/job_suite.log 2>&1 || { grep -a -v "^split precision" $O/job_suite.log | tail -40; exit 1; }
-grep -a "naive sampler, tiny\|config 3 reduced\|decidable selections" $O/job_suite.log; tail -1 $O/job_suite.log
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-python bench.py --steps 10 --warmup 2 > $O/job_bench.json 2> $O/job_bench.err || { tail -20 $O/job_bench.err; exit 1; }
-grep -a "bench +" $O/job_bench.err | grep -v " conv (" | cut -c1-400 | tail -30
+timeout -k 10 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_search.py -m gpu -q --timeout 300 -s -k "group_norm_split" > $O/job_x3.log 2>&1 || { grep -a "gn split" $O/job_x3.log; }
+grep -a "gn split" $O/job_x3.log; tail -1 $O/job_x3.log
+Q="--no-cpu-baseline --no-e2e --no-parity --no-subrecords --no-kernel-timing"
+timeout -k 10 300 python bench.py --steps 10 --warmup 2 --dtype f16x3 $Q 2> $O/job_bench_x3.err | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('f16x3', 'ms/step', d['ms_per_step'], 'evals/s', d['value'])" || { tail -20 $O/job_bench_x3.err; exit 1; }
