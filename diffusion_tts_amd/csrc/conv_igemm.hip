@@ -1593,7 +1593,12 @@ int conv_pick_pp(bool f32, const ConvP& p) {
   // search: 128 blocks of 27 tiles) is faster on the 8-wave implicit-GEMM kernel, whose 192 x 128 tiles give twice the blocks and need no
   // K split: 32 vs 41 us (profiles/r03_conv_variants.txt)
   const bool short_small = blocks_pp <= 128 && p.taps * (p.cin / 64) <= 27;
-  const bool auto_pp = p.taps == 9 && !short_small;     // (round 2 excluded residual layers with cin < 384: since the COMPUTE-side trims of round 3 the ping-pong kernel wins there too, profiles/r03_conv_variants.txt)
+  // a HALF round of the 128-cout form at 32x32 (DDPM++ CIFAR-32, 256 -> 256 at the 16 rows of BASELINE config 2: 128 blocks on 256 CUs)
+  // runs 38 us against 31 on the implicit-GEMM kernel, whose 128 x 128 tiles give twice the blocks: -4 % on that workload's step.  Keyed on
+  // the image size: the classifier's 16x16 layers are the same GEMM at 64 rows, but routed the same way they cost the ADM headline 0.5 %
+  // (their neighbours keep the operands of the ping-pong form warm; profiles/r03_small_batch_experiments.txt item 9c).
+  const bool half_round_128 = mt == 4 && blocks_pp > 64 && blocks_pp <= 128 && p.wout >= 32 && p.cout <= 256 && dts_knob_get(DTS_KNOB_CONV_HALF_ROUND) != 0;
+  const bool auto_pp = p.taps == 9 && !short_small && !half_round_128;     // (round 2 excluded residual layers with cin < 384: since the COMPUTE-side trims of round 3 the ping-pong kernel wins there too, profiles/r03_conv_variants.txt)
   return (auto_pp && blocks_pp >= 64) ? mt : 0;
 }
 

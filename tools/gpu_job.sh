@@ -2,9 +2,13 @@
 # scratch GPU job of the moment (one gpurun call): edit, run, read gpurun_out/job_*.  Committed form = the last job run.
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
-timeout -k 10 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_search.py -m gpu -q --timeout 300 -s -k "group_norm_split" > $O/job_x3.log 2>&1 || { grep -a "gn split" $O/job_x3.log; }
-grep -a "gn split" $O/job_x3.log; tail -1 $O/job_x3.log
 Q="--no-cpu-baseline --no-e2e --no-parity --no-subrecords --no-kernel-timing"
-timeout -k 10 300 python bench.py --steps 10 --warmup 2 --dtype f16x3 $Q 2> $O/job_bench_x3.err | python -c "
+for v in new old new old; do
+  if [ $v = old ]; then export DTS_CONV_HALF_ROUND=0; else unset DTS_CONV_HALF_ROUND; fi
+  timeout -k 10 300 python bench.py --workload ddpmpp32_rejection --steps 60 --warmup 5 $Q 2>/dev/null | python -c "
 import sys, json
-d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('f16x3', 'ms/step', d['ms_per_step'], 'evals/s', d['value'])" || { tail -20 $O/job_bench_x3.err; exit 1; }
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('ddpmpp32 $v', 'ms/step', d['ms_per_step'], 'evals/s', d['value'])" || exit 1
+  timeout -k 10 300 python bench.py --steps 20 --warmup 4 $Q 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('adm64 $v', 'ms/step', d['ms_per_step'], 'evals/s', d['value'])" || exit 1
+done
