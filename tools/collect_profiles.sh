@@ -5,6 +5,7 @@ cd "$(dirname "$0")/.."
 RD=${1:-r04}; O=gpurun_out
 cp "$(ls -t $O/final_prof/*/*kernel_stats.csv | head -1)" profiles/${RD}_bench_kernel_stats.csv
 cp "$(ls -t $O/final_prof_c8/*/*kernel_stats.csv | head -1)" profiles/${RD}_c8_kernel_stats.csv
+cp "$(ls -t $O/final_prof_x3/*/*kernel_stats.csv | head -1)" profiles/${RD}_f16x3_kernel_stats.csv
 grep "^{" $O/final_bench.json > profiles/${RD}_bench.json
 python - $O/final_hbm_traffic_pmc.json profiles/${RD}_hbm_traffic_pmc.json "$(git rev-parse --short HEAD)" <<'PY'
 import json, sys
@@ -16,7 +17,7 @@ cp $O/final_conv_sequence.json profiles/${RD}_conv_sequence.json
   echo "# (every input / weight / residual element read once, every output element written once).  x 'launches per step'; time and TFLOP/s from the in-process dispatch events."
   cat $O/final_pmc_per_shape.txt; } > profiles/${RD}_conv_per_shape_pmc.txt
 grep -v amdgpu.ids $O/final_bench.err > profiles/${RD}_bench_stderr_conv_table.txt
-for p in mcts:mcts_s256 2rank_gloo:2rank_gloo_one_gpu f16:f16 rccl1:rccl_one_rank; do
+for p in mcts:mcts_s256 2rank_gloo:2rank_gloo_one_gpu f16:f16 rccl1:rccl_one_rank f16x3:f16x3 f32:f32; do
   a=${p%%:*}; b=${p##*:}; grep "^{" $O/final_bench_$a.json > profiles/${RD}_bench_$b.json
 done
 for n in 1 2 4 8; do [ -f $O/final_scale_n$n.json ] && grep "^{" $O/final_scale_n$n.json > profiles/${RD}_scale_n$n.json; done
@@ -27,12 +28,26 @@ grep -v amdgpu.ids $O/final_vae.txt > profiles/${RD}_vae_decode.txt
 grep -v amdgpu.ids $O/final_att.txt > profiles/${RD}_attention.txt
 { echo "# tools/sd_bench.py on one MI355X: BASELINE config 4 with this build's parts (see profiles/r03_sd_config4.txt header in git history / DESIGN.md section 5)"
   grep "^SD beam" $O/final_sd.txt; } > profiles/${RD}_sd_config4_final.txt
-{ echo "# tools/conv_bench.py --n 64 --stats (with residual): 4-wave kernel | ping-pong kernel (shipped) | ping-pong with all 20 fragment reads in LOAD (the round-2 order)"
-  grep -v amdgpu $O/final_conv_variants_n64.txt
-  echo; echo "# tools/conv_bench.py --n 8 --stats: conv_igemm_kernel with 4 waves | with 8 waves (forced on every grid; the launcher picks it for grids <= 256 blocks) | ping-pong forced"
-  grep -v amdgpu $O/final_conv_variants_n8.txt; } > profiles/${RD}_conv_variants.txt
-{ echo "# tools/conv_stamps.py (second library built with -DDTS_STAMPS): in-kernel s_memtime stamps, per block median cycles; N = 64 rows, then 8 rows"
-  grep -v amdgpu $O/final_stamps_n64.txt; echo; grep -v amdgpu $O/final_stamps_n8.txt; } > profiles/${RD}_conv_stamps.txt
+grep -v amdgpu.ids $O/final_bench_f16x3.err > profiles/${RD}_bench_f16x3_stderr_conv_table.txt
+# rocprof average of the dominant kernel next to the in-process one, so that roofline.frac can be recomputed from profiles/ alone
+python - $RD <<'PY'
+import csv, json, sys
+rd = sys.argv[1]
+d = json.loads(open(f'profiles/{rd}_bench.json').read().strip().splitlines()[-1])
+r = d['roofline']
+rows = list(csv.DictReader(open(f'profiles/{rd}_bench_kernel_stats.csv')))
+dom = [x for x in rows if 'conv_pp_kernel<bf16_t, 9, 0, false, 6>' in x['Name']][0]
+rp_us = float(dom['AverageNs']) / 1e3
+out = {'kernel': dom['Name'], 'rocprofv3_avg_launch_us': round(rp_us, 2), 'rocprofv3_calls': int(dom['Calls']),
+       'in_process_avg_launch_us': r['avg_launch_us'], 'avg_launch_gflop': r['avg_launch_gflop'],
+       'frac_from_rocprofv3': round(r['avg_launch_gflop'] / rp_us * 1e3 / r['peak'], 4), 'frac_in_process': r['frac'],
+       'ratio_rocprof_over_in_process': round(rp_us / r['avg_launch_us'], 4),
+       'how': 'rocprofv3 --kernel-trace --stats of `bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-e2e --no-parity --no-subrecords` (same '
+              'workload, same graphs; a profiled process runs a few per cent slower: MI355X_MICROARCH.md DVFS item 2); in-process = HIP events attached to the '
+              'kernel\'s own dispatch in the default bench.py run'}
+json.dump(out, open(f'profiles/{rd}_dominant_kernel_rocprof_vs_inprocess.json', 'w'), indent=1)
+print(out)
+PY
 tail -2 $O/final_pytest.log
 python - $RD <<'PY'
 import json, sys
