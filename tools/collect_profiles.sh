@@ -36,7 +36,7 @@ rd = sys.argv[1]
 d = json.loads(open(f'profiles/{rd}_bench.json').read().strip().splitlines()[-1])
 r = d['roofline']
 rows = list(csv.DictReader(open(f'profiles/{rd}_bench_kernel_stats.csv')))
-dom = [x for x in rows if 'conv_pp_kernel<bf16_t, 9, 0, false, 6>' in x['Name']][0]
+dom = [x for x in rows if 'conv_pp_kernel<bf16_t, 9, 0, false, 6' in x['Name']][0]
 rp_us = float(dom['AverageNs']) / 1e3
 out = {'kernel': dom['Name'], 'rocprofv3_avg_launch_us': round(rp_us, 2), 'rocprofv3_calls': int(dom['Calls']),
        'in_process_avg_launch_us': r['avg_launch_us'], 'avg_launch_gflop': r['avg_launch_gflop'],
@@ -45,6 +45,17 @@ out = {'kernel': dom['Name'], 'rocprofv3_avg_launch_us': round(rp_us, 2), 'rocpr
        'how': 'rocprofv3 --kernel-trace --stats of `bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-e2e --no-parity --no-subrecords` (same '
               'workload, same graphs; a profiled process runs a few per cent slower: MI355X_MICROARCH.md DVFS item 2); in-process = HIP events attached to the '
               'kernel\'s own dispatch in the default bench.py run'}
+try:      # the SAME profiled process measured both ways (final_run.sh: final_prof_both)
+    import glob
+    b = json.loads([l for l in open('gpurun_out/final_prof_both.json') if l.startswith('{')][-1])['roofline']
+    rows2 = list(csv.DictReader(open(sorted(glob.glob('gpurun_out/final_prof_both/*/*kernel_stats.csv'))[-1])))
+    dom2 = [x for x in rows2 if 'conv_pp_kernel<bf16_t, 9, 0, false, 6' in x['Name']][0]
+    out['same_process'] = {'in_process_avg_launch_us': b['avg_launch_us'], 'rocprofv3_avg_launch_us': round(float(dom2['AverageNs']) / 1e3, 2),
+                           'ratio': round(float(dom2['AverageNs']) / 1e3 / b['avg_launch_us'], 4), 'frac_in_process': b['frac'],
+                           'note': 'one process under rocprofv3: HIP events attached to the dispatches (eager launches of the instrumented steps) vs the trace average over ALL '
+                                   'dispatches of that kernel in the process (graph replays + the instrumented eager steps)'}
+except Exception as e:
+    out['same_process'] = {'error': str(e)}
 json.dump(out, open(f'profiles/{rd}_dominant_kernel_rocprof_vs_inprocess.json', 'w'), indent=1)
 print(out)
 PY

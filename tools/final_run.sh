@@ -39,6 +39,8 @@ python tools/att_bench.py --n 64 > $O/final_att.txt 2>&1 || exit 1
 cd /tmp && export TMPDIR=/tmp
 Q="--no-cpu-baseline --no-kernel-timing --no-e2e --no-parity --no-subrecords"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/final_prof -- python3 $R/bench.py --steps 3 --warmup 1 $Q > $O/final_prof.log 2>&1 || exit 1
+# the SAME process measured both ways: bench.py's in-process per-dispatch HIP events (roofline.avg_launch_us in its JSON line) and rocprofv3's trace of those dispatches
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/final_prof_both -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-parity --no-subrecords > $O/final_prof_both.json 2> $O/final_prof_both.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/final_prof_c8 -- python3 $R/bench.py --steps 6 --warmup 1 --candidates 8 $Q > $O/final_prof_c8.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/final_prof_x3 -- python3 $R/bench.py --steps 3 --warmup 1 --dtype f16x3 $Q > $O/final_prof_x3.log 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/final_pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 $Q > $O/final_pmc_fetch.log 2>&1 || exit 1

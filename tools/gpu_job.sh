@@ -2,13 +2,8 @@
 # scratch GPU job of the moment (one gpurun call): edit, run, read gpurun_out/job_*.  Committed form = the last job run.
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
-Q="--no-cpu-baseline --no-e2e --no-parity --no-subrecords --no-kernel-timing"
-for v in new old new old; do
-  if [ $v = old ]; then export DTS_CONV_HALF_ROUND=0; else unset DTS_CONV_HALF_ROUND; fi
-  timeout -k 10 300 python bench.py --workload ddpmpp32_rejection --steps 60 --warmup 5 $Q 2>/dev/null | python -c "
-import sys, json
-d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('ddpmpp32 $v', 'ms/step', d['ms_per_step'], 'evals/s', d['value'])" || exit 1
-  timeout -k 10 300 python bench.py --steps 20 --warmup 4 $Q 2>/dev/null | python -c "
-import sys, json
-d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('adm64 $v', 'ms/step', d['ms_per_step'], 'evals/s', d['value'])" || exit 1
-done
+cd /tmp && export TMPDIR=/tmp
+rm -rf $O/final_prof_both
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/final_prof_both -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-parity --no-subrecords > $O/final_prof_both.json 2> $O/final_prof_both.err || { tail -5 $O/final_prof_both.err; exit 1; }
+find $O/final_prof_both -name "*kernel_trace.csv" -delete; find $O/final_prof_both -name "*.db" -delete
+grep "^{" $O/final_prof_both.json | cut -c1-300
