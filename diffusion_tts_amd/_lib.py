@@ -46,6 +46,8 @@ SIGNATURES = {
     'dts_edm_precond_in': [_p, _p, _i, _f, _p, _p, _i, _i, _p],
     'dts_edm_precond_out': [_p, _p, _p, _p, _i, _i, _p],
     'dts_split3_f16': [_p, _i, _p, _i, _p, _i64, _p],
+    'dts_split2_f16': [_p, _i, _p, _i64, _p],
+    'dts_attention_x3': [_p, _p, _i, _i, _i, _i, _f, _p],
     'dts_cast_from_f32': [_p, _p, _i, _i64, _p],
     'dts_cast_to_f32': [_p, _i, _p, _i64, _p],
     'dts_heun_xhat': [_p, _i, _i, _p, _i, _d, _p, _i, _i, _p],

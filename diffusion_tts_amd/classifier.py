@@ -100,7 +100,7 @@ class EncoderUNetModel:
         n, hh, ww, c = x.shape
         hn = ops.group_norm(x, 32, 1e-5, P.g, P.b, silu=False, split_out=self.x3)
         qkv = ops.conv2d(hn, P.wqkv, P.bqkv)
-        a = ops.attention(qkv.view(n, hh * ww, 3 * c), P.heads, 1.0 / math.sqrt(c // P.heads))
+        a = ops.attention(qkv.view(n, hh * ww, 3 * c), P.heads, 1.0 / math.sqrt(c // P.heads), x3=self.x3)
         return ops.conv2d(a.view(n, hh, ww, c), P.wproj, P.bproj, residual=x, gn_stats=True)
 
     @torch.no_grad()
@@ -131,5 +131,5 @@ class EncoderUNetModel:
         nt = tok.shape[1]
         qkv = ops.conv2d(tok.view(n, nt, 1, self.ch), self.pool_wqkv, self.pool_bqkv)
         heads = self.ch // self.cfg.num_head_channels
-        a = ops.attention(qkv.view(n, nt, 3 * self.ch), heads, 1.0 / math.sqrt(self.cfg.num_head_channels))
+        a = ops.attention(qkv.view(n, nt, 3 * self.ch), heads, 1.0 / math.sqrt(self.cfg.num_head_channels), x3=self.x3)
         return ops.linear(ops.take_token(a, 0), self.cproj_w, self.cproj_b)

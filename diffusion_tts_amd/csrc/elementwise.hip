@@ -540,6 +540,38 @@ __global__ __launch_bounds__(256) void split3_f16_kernel(const float* __restrict
   }
 }
 
+// split-precision attention input (dts_attention_x3): row p of x (C = c1 channels) -> hi(C) | lo'(C), the arithmetic of split3_f16_kernel
+__global__ __launch_bounds__(256) void split2_f16_kernel(const float* __restrict__ x, int C, uint4* __restrict__ out, long long rows) {
+  const int nch = C / 8;
+  const long long total = rows * nch;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const long long row = idx / nch;
+    const int ch = (int)(idx - row * nch);
+    const float* src = x + row * C + ch * 8;
+    const float4 a = reinterpret_cast<const float4*>(src)[0], b = reinterpret_cast<const float4*>(src)[1];
+    const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    float hi[8], lo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float h = f16_bits_to_f32(f32_to_f16_bits(f[e]));
+      if (fabsf(h) < 6.103515625e-05f) h = 0.f;
+      hi[e] = h;
+      lo[e] = (f[e] - h) * 2048.0f;
+    }
+    uint4* o = out + row * (2 * nch) + ch;
+    o[0] = pack16<f16_t>(hi); o[nch] = pack16<f16_t>(lo);
+  }
+}
+
+extern "C" int dts_split2_f16(const float* x, int c, void* out, int64_t rows, dts_stream s) {
+  DTS_CHECK_ARG(x && out && rows >= 0 && c > 0 && c % 8 == 0, "dts_split2_f16: bad args (c=%d)", c);
+  if (rows == 0) return DTS_OK;
+  ST;
+  hipLaunchKernelGGL(split2_f16_kernel, dim3(grid1d(rows * (c / 8))), dim3(256), 0, st, x, c, (uint4*)out, (long long)rows);
+  DTS_CHECK_LAUNCH("dts_split2_f16");
+  return DTS_OK;
+}
+
 extern "C" int dts_split3_f16(const float* x1, int c1, const float* x2, int c2, void* out, int64_t rows, dts_stream s) {
   DTS_CHECK_ARG(x1 && out && rows >= 0 && c1 > 0 && c1 % 8 == 0 && c2 >= 0 && c2 % 8 == 0, "dts_split3_f16: bad args (c1=%d c2=%d)", c1, c2);
   DTS_CHECK_ARG(c2 == 0 || x2, "dts_split3_f16: c2 without x2");

@@ -198,7 +198,7 @@ class EDMPrecond:
             n, hh, ww, c = x.shape
             hn = ops.group_norm(x, G(c), self.eps, P.g2, P.b2, silu=False, split_out=self.x3)
             qkv = ops.conv2d(hn, P.wqkv, P.bqkv)
-            a = ops.attention(qkv.view(n, hh * ww, 3 * c), b.heads, 1.0 / math.sqrt(c // b.heads))
+            a = ops.attention(qkv.view(n, hh * ww, 3 * c), b.heads, 1.0 / math.sqrt(c // b.heads), x3=self.x3)
             x = ops.conv2d(a.view(n, hh, ww, c), P.wproj, P.bproj, residual=x, out_scale=self.skip_scale, gn_stats=True)
         return x
 

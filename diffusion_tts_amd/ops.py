@@ -351,12 +351,18 @@ def resample2x(x, up):
 
 
 # ---- attention ----------------------------------------------------------------------------------
-def attention(qkv, heads, scale):
-    """qkv [n, t, 3*heads*d] (q|k|v blocks) -> [n, t, heads*d]."""
+def attention(qkv, heads, scale, x3=False):
+    """qkv [n, t, 3*heads*d] (q|k|v blocks) -> [n, t, heads*d].  x3 (split-precision mode, float32 qkv, head dim 64): Q.K^T and P.V on the
+    16-bit matrix cores with hi/lo operand pairs (dts_attention_x3) instead of the f32 matrix instruction; same accuracy."""
     n, t, c3 = qkv.shape
     c = c3 // 3
     d = c // heads
     out = torch.empty((n, t, c), dtype=qkv.dtype, device=qkv.device)
+    if x3 and d == 64 and qkv.dtype == torch.float32:
+        sp = torch.empty((n, t, 2 * c3), dtype=torch.float16, device=qkv.device)
+        _call('dts_split2_f16', _ptr(qkv, 'qkv', torch.float32), c3, _ptr(sp), n * t)
+        _call('dts_attention_x3', _ptr(sp), _ptr(out), n, t, heads, d, float(scale))
+        return out
     _call('dts_attention', _ptr(qkv), _ptr(out), dt_code(qkv.dtype), n, t, heads, d, float(scale))
     return out
 

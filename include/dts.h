@@ -41,7 +41,7 @@ enum dts_status { DTS_OK = 0, DTS_ERR_ARG = -1, DTS_ERR_LAUNCH = -2, DTS_ERR_UNS
 
 #define DTS_ABI_VERSION 108        /* bumped with every change of a signature or of dts_conv_args (101: ev_start/ev_stop; 102: tuning knobs; 103: dts_cosine_rows; 104: dts_nchw_to_nhwc_pad,
                                      105: dts_conv_args.gn_coef / gn_silu, dts_conv_fuses_gn;
-                                     head dim 512 in dts_attention; 106: dts_conv_kernel, 128-cout ping-pong blocks; 107: dts_resample_u8, dts_lut_u8_f32; 108: DTS_F16X3, dts_conv_args.acc_scale, dts_split3_f16, dts_gn_apply_x3) */
+                                     head dim 512 in dts_attention; 106: dts_conv_kernel, 128-cout ping-pong blocks; 107: dts_resample_u8, dts_lut_u8_f32; 108: DTS_F16X3, dts_conv_args.acc_scale, dts_split3_f16, dts_gn_apply_x3, dts_split2_f16, dts_attention_x3) */
 int dts_version(void);            /* == DTS_ABI_VERSION of the build; a binding must refuse any other value */
 const char* dts_last_error(void);
 /* Tuning knobs (measurement aid; a knob only selects between kernels / block orders / ring depths that give correct results -- the
@@ -142,6 +142,10 @@ int dts_resample2x(const void* x, void* out, int dtype, int n, int h, int w, int
 /* qkv NHWC-flattened [n][t][3*heads*d] laid out q[heads][d] | k[heads][d] | v[heads][d];
  * out [n][t][heads*d]; softmax(q.k * scale) in f32. d in {64,128,256} (and 512 in the 16-bit types: the SD VAE's mid block); any t >= 1. */
 int dts_attention(const void* qkv, void* out, int dtype, int n, int t, int heads, int d, float scale, dts_stream s);
+/* the same attention in the split-precision mode (DTS_F16X3; d = 64): qkv_split = dts_split2_f16 of the f32 qkv tensor, f16 [n][t][6*heads*d] =
+ * hi(3C) | lo'(3C) per token; out f32 [n][t][heads*d].  Q.K^T and P.V on the 16-bit matrix cores with hi/lo operand pairs (the lo*lo term,
+ * 2^-22, dropped), softmax in f32: the f32 kernel's accuracy without the f32 matrix instruction's 1/16 rate. */
+int dts_attention_x3(const void* qkv_split, float* out, int n, int t, int heads, int d, float scale, dts_stream s);
 
 /* ---- K7/K8: embedding MLP pieces and EDM preconditioning (networks.py:200-206,437-447,654-668) ---- */
 /* y[m][n] = act_out( act_in(x[m][:]) . w[n][:] + bias[n] (+ y[m][n] if accumulate) ); all f32; act: 0 none, 1 SiLU */
@@ -158,6 +162,8 @@ int dts_edm_precond_out(const double* x, const float* F, const float* coef, floa
  * concat(x1, x2)[p][:] (f32 rows of c1 / c2 channels, x2 may be NULL with c2 = 0; C = c1 + c2, multiples of 8), hi = f16(x) (0 when that
  * would be subnormal), lo = f16((x - hi) * 2^11). */
 int dts_split3_f16(const float* x1, int c1, const float* x2, int c2, void* out, int64_t rows, dts_stream s);
+/* out[p][0:c] = hi, [c:2c] = lo * 2^11 of x[p][:] (the operand image of dts_attention_x3) */
+int dts_split2_f16(const float* x, int c, void* out, int64_t rows, dts_stream s);
 /* f32 -> dtype cast of a dense array (embedding -> activation dtype) and back */
 int dts_cast_from_f32(const float* src, void* dst, int dtype, int64_t count, dts_stream s);
 int dts_cast_to_f32(const void* src, int dtype, float* dst, int64_t count, dts_stream s);

@@ -529,6 +529,29 @@ def test_attention(ops, dtype, shape):
     assert rel_err(out, ref) < (3e-5 if dtype == torch.float32 else TOL[dtype])
 
 
+@pytest.mark.parametrize('shape', [(2, 64, 2), (1, 256, 3), (2, 65, 2), (3, 1, 1), (1, 1024, 2), (2, 130, 12)])
+@pytest.mark.parametrize('spread', [1.0, 4.0, 0.01])
+def test_attention_split_precision(ops, shape, spread):
+    """ops.attention(..., x3=True) (dts_split2_f16 + dts_attention_x3, head dim 64): Q.K^T and P.V on the 16-bit matrix cores with hi/lo
+    operand pairs.  Against an f64 reference it must be as close as the f32 kernel (not f16's 2^-11): full, ragged and one-token
+    sequences; sharp softmaxes (spread 4: logits of +-30, most probabilities below the f16 normal range) and near-uniform ones with tiny
+    operands (spread 0.01: every lo part is f16-subnormal before its 2^11 scaling)."""
+    n, t, heads = shape
+    d, gen = 64, g(61)
+    c = heads * d
+    qkv = torch.randn(n, t, 3 * c, generator=gen) * spread
+    q64, k64, v64 = (qkv[..., i * c:(i + 1) * c].double().reshape(n, t, heads, d).permute(0, 2, 1, 3) for i in range(3))
+    w = torch.softmax(q64 @ k64.transpose(-1, -2) / math.sqrt(d), dim=-1)
+    ref = (w @ v64).permute(0, 2, 1, 3).reshape(n, t, c)
+    x = qkv.to(DEV)
+    got3 = ops.attention(x, heads, 1.0 / math.sqrt(d), x3=True).double().cpu()
+    got32 = ops.attention(x, heads, 1.0 / math.sqrt(d)).double().cpu()
+    scale = float(ref.abs().max())
+    e3, e32 = float((got3 - ref).abs().max()) / scale, float((got32 - ref).abs().max()) / scale
+    print(f'split-precision attention n={n} t={t} heads={heads} spread={spread}: rel err {e3:.2e} (f32 kernel {e32:.2e})')
+    assert e3 < max(1e-6, 1.25 * e32), (e3, e32)      # (measured: 0.4x ... 0.7x the f32 kernel's error everywhere; sharp softmaxes amplify both)
+
+
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('t', [64, 200, 1024])
 def test_attention_head_dim_512(ops, dtype, t):

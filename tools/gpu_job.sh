@@ -2,8 +2,9 @@
 # scratch GPU job of the moment (one gpurun call): edit, run, read gpurun_out/job_*.  Committed form = the last job run.
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
-cd /tmp && export TMPDIR=/tmp
-rm -rf $O/final_prof_both
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/final_prof_both -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-parity --no-subrecords > $O/final_prof_both.json 2> $O/final_prof_both.err || { tail -5 $O/final_prof_both.err; exit 1; }
-find $O/final_prof_both -name "*kernel_trace.csv" -delete; find $O/final_prof_both -name "*.db" -delete
-grep "^{" $O/final_prof_both.json | cut -c1-300
+timeout -k 10 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_search.py tests/test_abi.py -q --timeout 300 -s -k "attention_split or search_parity or denoiser_forward or classifier_and or abi or symbol" > $O/job_x3.log 2>&1 || { grep -a "split-precision attention" $O/job_x3.log | cut -c1-200; tail -30 $O/job_x3.log | cut -c1-300; exit 1; }
+grep -a "split-precision attention" $O/job_x3.log | sed 's/^\.*//' | cut -c1-200; tail -1 $O/job_x3.log
+Q="--no-cpu-baseline --no-e2e --no-parity --no-subrecords --no-kernel-timing"
+timeout -k 10 300 python bench.py --steps 10 --warmup 2 --dtype f16x3 $Q 2> $O/job_bench_x3.err | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('f16x3', 'ms/step', d['ms_per_step'], 'evals/s', d['value'])" || { tail -20 $O/job_bench_x3.err; exit 1; }
