@@ -405,14 +405,16 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
 // ------------------------------------------------------------------------------------------------
 // Split-precision attention (dts.h DTS_F16X3; head dim 64): the f32 attention's accuracy on the 16-bit matrix cores.  attention32_kernel
 // is bound by the f32 matrix instruction (1/16 of the f16 rate): 0.66 ms at best for the ADM 32x32 level at 64 rows, 17 % of a
-// split-precision search iteration.  Here every operand is an f16 pair hi + lo * 2^-11 (hi = f16(x), lo' = (x - hi) * 2^11: the input is the
-// image dts_split2_f16 makes of the f32 qkv tensor, [hi(3C) | lo'(3C)] per token) and every product x*y ~ xh*yh + 2^-11 (xl'*yh + xh*yl')
-// -- the lo*lo term (2^-22) is dropped -- with the 2^-11 applied ONCE to a second accumulator set instead of to an operand (the matrix
-// cores flush f16 subnormals, so operands must stay in the normal range):
-//   S^T = Kh.Qh^T  +  2^-11 (Kh.Ql'^T + Kl'.Qh^T)              main + cross accumulators, combined before the softmax
-//   P (f32, after exp2) -> ph = f16(p) (0 below 2^-14: the whole value then rides in pl'), pl' = f16((p - ph) * 2^11)
-//   O^T = Vh^T.ph  +  2^-11 (Vh^T.pl' + Vl'^T.ph),   l likewise with an all-ones A operand
-// Structure, LDS rows (K' = Kh | Kl', V' = Vh | Vl': 256 B + 32 B pad), register prefetch and the transposed V reads are attention16_kernel's.
+// split-precision search iteration.  Here every operand is an f16 pair hi + lo (hi = f16(y), lo = f16(y - hi)) of a value y = x * 2^k, and
+// every product x*y ~ xh*yh + xl*yh + xh*yl (the lo*lo term, 2^-22, is dropped) accumulates in ONE f32 accumulator.  The powers of two keep
+// the lo parts NORMAL f16 numbers -- the matrix cores flush subnormal inputs -- and come out again exactly:
+//   q, k, v arrive as the image dts_split2_f16 makes of the f32 qkv tensor: hi(3C) | lo(3C) of x * 2^6 per token (|x| < 1023; the lo part
+//     of an |x| below 2^-8 is lost: <= 2^-20 |x|, a few such elements per dot product);
+//   S^T * 2^12 = Kh.Qh^T + Kh.Ql^T + Kl.Qh^T, the 2^-12 folded into the softmax scale;
+//   P (f32 in [0,1] after exp2) * 2^14 -> ph, pl in registers;  O^T * 2^20 = Vh^T.ph + Vh^T.pl + Vl^T.ph,  l * 2^14 = ones.ph + ones.pl.
+// Structure, LDS rows (K' = Kh | Kl, V' = Vh | Vl: 256 B + 32 B pad), register prefetch, QT query tiles per wave and the transposed V
+// reads are attention16_kernel's; three MFMAs per fragment pair instead of one, and the fragment reads are what bounds it (QT = 2 halves them).
+template <int QT>
 __global__ __launch_bounds__(256) void attention_x3_kernel(const AttP p) {
   using T = f16_t;
   constexpr int D = 64, ES = 2, ROWB = 2 * D * ES + 32, CH = 2 * D / 8, KSTEPS = D / 32, DT = D / 16, NCH = (64 * CH) / 256;
@@ -425,29 +427,35 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const AttP p) {
   att_block(p, nh, qblk);
   const int n = nh / p.heads, head = nh - n * p.heads;
   const int C = p.heads * D;
-  const size_t rowstride = (size_t)6 * C * ES;           // hi(3C) | lo'(3C)
-  const size_t LO = (size_t)3 * C * ES;                  // byte offset of the lo' planes inside a token row
+  const size_t rowstride = (size_t)6 * C * ES;           // hi(3C) | lo(3C)
+  const size_t LO = (size_t)3 * C * ES;                  // byte offset of the lo planes inside a token row
   const char* base = p.qkv + (size_t)n * p.t * rowstride + (size_t)head * D * ES;
-  const int q0 = qblk * 64 + wid * 16, qrow = q0 + lq;
-  uint4 qh[KSTEPS], ql[KSTEPS];
+  const int q0 = qblk * (64 * QT) + wid * (16 * QT);
+  uint4 qh[QT][KSTEPS], ql[QT][KSTEPS];
 #pragma unroll
-  for (int s = 0; s < KSTEPS; ++s) {
-    qh[s] = ql[s] = make_uint4(0, 0, 0, 0);
-    if (qrow < p.t) {
-      qh[s] = *reinterpret_cast<const uint4*>(base + (size_t)qrow * rowstride + (lg + 4 * s) * 16);
-      ql[s] = *reinterpret_cast<const uint4*>(base + (size_t)qrow * rowstride + LO + (lg + 4 * s) * 16);
+  for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      const int qrow = q0 + qt * 16 + lq;
+      qh[qt][s] = ql[qt][s] = make_uint4(0, 0, 0, 0);
+      if (qrow < p.t) {
+        qh[qt][s] = *reinterpret_cast<const uint4*>(base + (size_t)qrow * rowstride + (lg + 4 * s) * 16);
+        ql[qt][s] = *reinterpret_cast<const uint4*>(base + (size_t)qrow * rowstride + LO + (lg + 4 * s) * 16);
+      }
     }
-  }
-  const float sc2 = p.scale_log2e;
-  constexpr float LOS = 1.0f / 2048.0f;
-  f32x4_t om[DT], oc[DT], lm = {0.f, 0.f, 0.f, 0.f}, lc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < DT; ++i) { om[i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; oc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  const float sc2 = p.scale_log2e * (1.0f / 4096.0f);    // the accumulators hold S * 2^12 (q and k carry 2^6 each)
+  f32x4_t o[QT][DT], ol[QT];
   const uint4 ones = make_uint4(AttMma<T>::ONES2, AttMma<T>::ONES2, AttMma<T>::ONES2, AttMma<T>::ONES2);
-  float m_run = -INFINITY;
+  float m_run[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    m_run[qt] = -INFINITY; ol[qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[qt][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
   const int ntiles = (p.t + 63) / 64;
   uint4 pk[NCH], pv[NCH];
-  // chunk c of a K' / V' row: c < 8 -> hi plane chunk c, else lo' plane chunk c - 8
+  // chunk c of a K' / V' row: c < 8 -> hi plane chunk c, else lo plane chunk c - 8
 #define X3_LOAD_TILE(key0_)                                                                      \
   _Pragma("unroll") for (int u = 0; u < NCH; ++u) {                                               \
     const int idx = tid + 256 * u, r = idx / CH, c = idx - r * CH;                                \
@@ -471,75 +479,83 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const AttP p) {
     X3_STAGE_TILE();
     __syncthreads();
     if (kt + 1 < ntiles) { X3_LOAD_TILE(key0 + 64); }
-    // ---- S^T = main + 2^-11 cross
-    f32x4_t sm[4], sc[4];
+    // ---- S^T * 2^12: a K fragment pair feeds every query tile
+    f32x4_t sacc[QT][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      sm[j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; sc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) sacc[qt][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < KSTEPS; ++s) {
         const uint4 kh = *reinterpret_cast<const uint4*>(sK + (j * 16 + lq) * ROWB + (lg + 4 * s) * 16);
         const uint4 kl = *reinterpret_cast<const uint4*>(sK + (j * 16 + lq) * ROWB + D * ES + (lg + 4 * s) * 16);
-        sm[j] = AttMma<T>::run(kh, qh[s], sm[j]);
-        sc[j] = AttMma<T>::run(kh, ql[s], sc[j]);
-        sc[j] = AttMma<T>::run(kl, qh[s], sc[j]);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          sacc[qt][j] = AttMma<T>::run(kh, qh[qt][s], sacc[qt][j]);
+          sacc[qt][j] = AttMma<T>::run(kh, ql[qt][s], sacc[qt][j]);
+          sacc[qt][j] = AttMma<T>::run(kl, qh[qt][s], sacc[qt][j]);
+        }
       }
     }
-    float sv[4][4];
+    // ---- online softmax (attention16_kernel's), then P * 2^14 as (hi, lo) operand pairs
+    uint4 pbh[QT][2], pbl[QT][2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int qt = 0; qt < QT; ++qt) {
+      if (key0 + 64 > p.t) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        sv[j][r] = fmaf(sc[j][r], LOS, sm[j][r]);
-        if (key0 + 64 > p.t && key0 + j * 16 + lg * 4 + r >= p.t) sv[j][r] = -INFINITY;
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (key0 + j * 16 + lg * 4 + r >= p.t) sacc[qt][j][r] = -INFINITY;
       }
-    float tmax = vmax3(sv[0][0], sv[0][1], sv[0][2]);
-    tmax = vmax3(tmax, sv[0][3], sv[1][0]);
-    tmax = vmax3(tmax, sv[1][1], sv[1][2]);
-    tmax = vmax3(tmax, sv[1][3], sv[2][0]);
-    tmax = vmax3(tmax, sv[2][1], sv[2][2]);
-    tmax = vmax3(tmax, sv[2][3], sv[3][0]);
-    tmax = vmax3(tmax, sv[3][1], sv[3][2]);
-    tmax = vmax2(tmax, sv[3][3]);
-    tmax = vmax2(tmax, __shfl_xor(tmax, 16, 64));
-    tmax = vmax2(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = vmax2(m_run, tmax);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * sc2);
-    const float mb = m_new * sc2;
-    m_run = m_new;
-    if (!__all(alpha == 1.0f)) {
+      float tmax = vmax3(sacc[qt][0][0], sacc[qt][0][1], sacc[qt][0][2]);
+      tmax = vmax3(tmax, sacc[qt][0][3], sacc[qt][1][0]);
+      tmax = vmax3(tmax, sacc[qt][1][1], sacc[qt][1][2]);
+      tmax = vmax3(tmax, sacc[qt][1][3], sacc[qt][2][0]);
+      tmax = vmax3(tmax, sacc[qt][2][1], sacc[qt][2][2]);
+      tmax = vmax3(tmax, sacc[qt][2][3], sacc[qt][3][0]);
+      tmax = vmax3(tmax, sacc[qt][3][1], sacc[qt][3][2]);
+      tmax = vmax2(tmax, sacc[qt][3][3]);
+      tmax = vmax2(tmax, __shfl_xor(tmax, 16, 64));
+      tmax = vmax2(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = vmax2(m_run[qt], tmax);
+      const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * sc2);
+      const float mb = m_new * sc2 - 14.0f;             // exp2(.. + 14): P * 2^14 straight out of the exponential
+      m_run[qt] = m_new;
+      if (!__all(alpha == 1.0f)) {
 #pragma unroll
-      for (int i = 0; i < DT; ++i) { om[i] *= alpha; oc[i] *= alpha; }
-      lm[0] *= alpha; lc[0] *= alpha;
-    }
-    // ---- P -> (ph, pl') pairs; k-slot layout as in attention16_kernel
-    float ph[4][4], pl[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = __builtin_amdgcn_exp2f(fmaf(sv[j][r], sc2, -mb));
-        float h = f16_bits_to_f32(f32_to_f16_bits(e));
-        if (h < 6.103515625e-05f) h = 0.f;              // a subnormal hi would be flushed by the matrix core: carry the value in the lo plane
-        ph[j][r] = h;
-        pl[j][r] = (e - h) * 2048.0f;
+        for (int i = 0; i < DT; ++i) o[qt][i] *= alpha;
+        ol[qt][0] *= alpha;
       }
-    uint4 pbh[2], pbl[2];
+      float ph[4][4], pl[4][4];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      pbh[kk].x = pack2_f16(ph[2 * kk][0], ph[2 * kk][1]);         pbh[kk].y = pack2_f16(ph[2 * kk][2], ph[2 * kk][3]);
-      pbh[kk].z = pack2_f16(ph[2 * kk + 1][0], ph[2 * kk + 1][1]); pbh[kk].w = pack2_f16(ph[2 * kk + 1][2], ph[2 * kk + 1][3]);
-      pbl[kk].x = pack2_f16(pl[2 * kk][0], pl[2 * kk][1]);         pbl[kk].y = pack2_f16(pl[2 * kk][2], pl[2 * kk][3]);
-      pbl[kk].z = pack2_f16(pl[2 * kk + 1][0], pl[2 * kk + 1][1]); pbl[kk].w = pack2_f16(pl[2 * kk + 1][2], pl[2 * kk + 1][3]);
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(fmaf(sacc[qt][j][r], sc2, -mb));
+          const float h = f16_bits_to_f32(f32_to_f16_bits(e));
+          ph[j][r] = h;
+          pl[j][r] = e - h;
+        }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        pbh[qt][kk].x = pack2_f16(ph[2 * kk][0], ph[2 * kk][1]);         pbh[qt][kk].y = pack2_f16(ph[2 * kk][2], ph[2 * kk][3]);
+        pbh[qt][kk].z = pack2_f16(ph[2 * kk + 1][0], ph[2 * kk + 1][1]); pbh[qt][kk].w = pack2_f16(ph[2 * kk + 1][2], ph[2 * kk + 1][3]);
+        pbl[qt][kk].x = pack2_f16(pl[2 * kk][0], pl[2 * kk][1]);         pbl[qt][kk].y = pack2_f16(pl[2 * kk][2], pl[2 * kk][3]);
+        pbl[qt][kk].z = pack2_f16(pl[2 * kk + 1][0], pl[2 * kk + 1][1]); pbl[qt][kk].w = pack2_f16(pl[2 * kk + 1][2], pl[2 * kk + 1][3]);
+      }
     }
-    // ---- O^T and l: main + 2^-11 cross
+    // ---- O^T * 2^20 and l * 2^14; a V^T fragment pair feeds every query tile
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int rq = (lane & 15) >> 2, rp = lane & 3;
       const char* va = sV + (32 * kk + 4 * lg + rq) * ROWB + rp * 8;
       const char* vb = va + 16 * ROWB;
-      lm = AttMma<T>::run(ones, pbh[kk], lm);
-      lc = AttMma<T>::run(ones, pbl[kk], lc);
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        ol[qt] = AttMma<T>::run(ones, pbh[qt][kk], ol[qt]);
+        ol[qt] = AttMma<T>::run(ones, pbl[qt][kk], ol[qt]);
+      }
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         const uint2 h0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(va + dt * 32)));
@@ -547,23 +563,26 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const AttP p) {
         const uint2 l0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(va + D * ES + dt * 32)));
         const uint2 l1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vb + D * ES + dt * 32)));
         const uint4 avh = make_uint4(h0.x, h0.y, h1.x, h1.y), avl = make_uint4(l0.x, l0.y, l1.x, l1.y);
-        om[dt] = AttMma<T>::run(avh, pbh[kk], om[dt]);
-        oc[dt] = AttMma<T>::run(avh, pbl[kk], oc[dt]);
-        oc[dt] = AttMma<T>::run(avl, pbh[kk], oc[dt]);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          o[qt][dt] = AttMma<T>::run(avh, pbh[qt][kk], o[qt][dt]);
+          o[qt][dt] = AttMma<T>::run(avh, pbl[qt][kk], o[qt][dt]);
+          o[qt][dt] = AttMma<T>::run(avl, pbh[qt][kk], o[qt][dt]);
+        }
       }
     }
   }
 #undef X3_LOAD_TILE
 #undef X3_STAGE_TILE
-  if (qrow < p.t) {
-    const float inv = 1.f / fmaf(lc[0], LOS, lm[0]);
-    float* orow = reinterpret_cast<float*>(p.out) + ((size_t)n * p.t + qrow) * C + head * D;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-      float4 v;
-      v.x = fmaf(oc[dt][0], LOS, om[dt][0]) * inv; v.y = fmaf(oc[dt][1], LOS, om[dt][1]) * inv;
-      v.z = fmaf(oc[dt][2], LOS, om[dt][2]) * inv; v.w = fmaf(oc[dt][3], LOS, om[dt][3]) * inv;
-      *reinterpret_cast<float4*>(orow + dt * 16 + lg * 4) = v;
+  for (int qt = 0; qt < QT; ++qt) {
+    const int qrow = q0 + qt * 16 + lq;
+    if (qrow < p.t) {
+      const float inv = (1.0f / 64.0f) / ol[qt][0];      // (O * 2^20) / (l * 2^14) = 2^6 * O  (v carries 2^6)
+      float* orow = reinterpret_cast<float*>(p.out) + ((size_t)n * p.t + qrow) * C + head * D;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+        *reinterpret_cast<float4*>(orow + dt * 16 + lg * 4) = make_float4(o[qt][dt][0] * inv, o[qt][dt][1] * inv, o[qt][dt][2] * inv, o[qt][dt][3] * inv);
     }
   }
 }
@@ -746,7 +765,10 @@ extern "C" int dts_attention_x3(const void* qkv_split, float* out, int n, int t,
   DTS_CHECK_ARG(n > 0 && t > 0 && heads > 0, "dts_attention_x3: bad shape");
   DTS_CHECK_ARG(d == 64, "dts_attention_x3: head dim %d unsupported (64; other sizes take dts_attention in DTS_F32)", d);
   AttP p{(const char*)qkv_split, (char*)out, n, t, heads, d, scale * 1.4426950408889634f, 0, 1};
-  return launch_att(attention_x3_kernel, p, (size_t)2 * 64 * (2 * 64 * 2 + 32), to_stream(s));
+  const size_t lds = (size_t)2 * 64 * (2 * 64 * 2 + 32);
+  // two query tiles per wave once the sequence is long enough to keep >= 2 blocks per CU in the grid (the rule of the 16-bit kernel)
+  if (t >= 256 && (long long)((t + 127) / 128) * n * heads >= 512) return launch_att(attention_x3_kernel<2>, p, lds, to_stream(s), 128);
+  return launch_att(attention_x3_kernel<1>, p, lds, to_stream(s));
 }
 
 extern "C" int dts_attention(const void* qkv, void* out, int dtype, int n, int t, int heads, int d, float scale, dts_stream s) {

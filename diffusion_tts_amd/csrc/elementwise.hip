@@ -540,7 +540,9 @@ __global__ __launch_bounds__(256) void split3_f16_kernel(const float* __restrict
   }
 }
 
-// split-precision attention input (dts_attention_x3): row p of x (C = c1 channels) -> hi(C) | lo'(C), the arithmetic of split3_f16_kernel
+// split-precision attention input (dts_attention_x3): row p of x (C channels) -> hi(C) | lo(C) of x * 2^6, hi = f16(y), lo = f16(y - hi).
+// The factor keeps the lo part a normal f16 number for |x| >= 2^-8 (the matrix cores flush subnormal inputs; below that the lo part,
+// <= 2^-20 |x|, is lost) and |x| must stay below 1023; the attention kernel takes the powers of two out again exactly.
 __global__ __launch_bounds__(256) void split2_f16_kernel(const float* __restrict__ x, int C, uint4* __restrict__ out, long long rows) {
   const int nch = C / 8;
   const long long total = rows * nch;
@@ -553,10 +555,9 @@ __global__ __launch_bounds__(256) void split2_f16_kernel(const float* __restrict
     float hi[8], lo[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float h = f16_bits_to_f32(f32_to_f16_bits(f[e]));
-      if (fabsf(h) < 6.103515625e-05f) h = 0.f;
-      hi[e] = h;
-      lo[e] = (f[e] - h) * 2048.0f;
+      const float y = f[e] * 64.0f;
+      hi[e] = f16_bits_to_f32(f32_to_f16_bits(y));
+      lo[e] = y - hi[e];
     }
     uint4* o = out + row * (2 * nch) + ch;
     o[0] = pack16<f16_t>(hi); o[nch] = pack16<f16_t>(lo);

@@ -358,7 +358,8 @@ def attention(qkv, heads, scale, x3=False):
     c = c3 // 3
     d = c // heads
     out = torch.empty((n, t, c), dtype=qkv.dtype, device=qkv.device)
-    if x3 and d == 64 and qkv.dtype == torch.float32:
+    # (short sequences stay on the f32 kernel: at T = 64 the split pass alone costs what that launch does -- tools/att_bench.py --x3)
+    if x3 and d == 64 and t >= 128 and qkv.dtype == torch.float32:
         sp = torch.empty((n, t, 2 * c3), dtype=torch.float16, device=qkv.device)
         _call('dts_split2_f16', _ptr(qkv, 'qkv', torch.float32), c3, _ptr(sp), n * t)
         _call('dts_attention_x3', _ptr(sp), _ptr(out), n, t, heads, d, float(scale))

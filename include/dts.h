@@ -143,7 +143,7 @@ int dts_resample2x(const void* x, void* out, int dtype, int n, int h, int w, int
  * out [n][t][heads*d]; softmax(q.k * scale) in f32. d in {64,128,256} (and 512 in the 16-bit types: the SD VAE's mid block); any t >= 1. */
 int dts_attention(const void* qkv, void* out, int dtype, int n, int t, int heads, int d, float scale, dts_stream s);
 /* the same attention in the split-precision mode (DTS_F16X3; d = 64): qkv_split = dts_split2_f16 of the f32 qkv tensor, f16 [n][t][6*heads*d] =
- * hi(3C) | lo'(3C) per token; out f32 [n][t][heads*d].  Q.K^T and P.V on the 16-bit matrix cores with hi/lo operand pairs (the lo*lo term,
+ * hi(3C) | lo(3C) per token; out f32 [n][t][heads*d].  Q.K^T and P.V on the 16-bit matrix cores with hi/lo operand pairs (the lo*lo term,
  * 2^-22, dropped), softmax in f32: the f32 kernel's accuracy without the f32 matrix instruction's 1/16 rate. */
 int dts_attention_x3(const void* qkv_split, float* out, int n, int t, int heads, int d, float scale, dts_stream s);
 
@@ -162,7 +162,7 @@ int dts_edm_precond_out(const double* x, const float* F, const float* coef, floa
  * concat(x1, x2)[p][:] (f32 rows of c1 / c2 channels, x2 may be NULL with c2 = 0; C = c1 + c2, multiples of 8), hi = f16(x) (0 when that
  * would be subnormal), lo = f16((x - hi) * 2^11). */
 int dts_split3_f16(const float* x1, int c1, const float* x2, int c2, void* out, int64_t rows, dts_stream s);
-/* out[p][0:c] = hi, [c:2c] = lo * 2^11 of x[p][:] (the operand image of dts_attention_x3) */
+/* out[p][0:c] = hi, [c:2c] = lo of x[p][:] * 2^6 (hi = f16(y), lo = f16(y - hi); |x| < 1023): the operand image of dts_attention_x3 */
 int dts_split2_f16(const float* x, int c, void* out, int64_t rows, dts_stream s);
 /* f32 -> dtype cast of a dense array (embedding -> activation dtype) and back */
 int dts_cast_from_f32(const float* src, void* dst, int dtype, int64_t count, dts_stream s);

@@ -20,14 +20,44 @@ SHAPES = [  # (name, tokens, heads, head_dim)
 ]
 
 
+def x3_table(a):
+    print('f32 qkv, per launch: attention32_kernel (f32 MFMA) | split-precision path = dts_split2_f16 + attention_x3_kernel | the f16 kernel for scale')
+    for name, t, heads, d in SHAPES:
+        if d != 64:
+            continue
+        c = heads * d
+        qkv = torch.randn(a.n, t, 3 * c, device='cuda')
+        q16 = qkv.half()
+        fl = 4.0 * a.n * heads * t * t * d
+        res = []
+        for fn in (lambda: ops.attention(qkv, heads, d ** -0.5), lambda: ops.attention(qkv, heads, d ** -0.5, x3=True), lambda: ops.attention(q16, heads, d ** -0.5)):
+            for _ in range(2):
+                fn()
+            ts = []
+            for r in range(a.rounds):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda._sleep(200_000)
+                e0.record()
+                for _ in range(4):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) / 4)
+            res.append(sorted(ts)[len(ts) // 2])
+        print(f'{name:20s} T={t:5d} | f32 {res[0] * 1e3:7.1f} us {fl / res[0] / 1e9:6.1f} TF/s | f16x3 {res[1] * 1e3:7.1f} us {fl / res[1] / 1e9:6.1f} TF/s (algorithmic) | f16 {res[2] * 1e3:7.1f} us', flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--n', type=int, default=64)
     ap.add_argument('--dtype', default='bf16')
     ap.add_argument('--rounds', type=int, default=9)
     ap.add_argument('--variants', nargs='*', default=['att_xcd=0', 'att_xcd=1'])
+    ap.add_argument('--x3', action='store_true', help='f32 qkv: the f32-MFMA kernel vs the split-precision kernel (split pass included)')
     a = ap.parse_args()
     dt = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[a.dtype]
+    if a.x3:
+        return x3_table(a)
     variants = [dict((kv.split('=')[0], int(kv.split('=')[1])) for kv in v.split(',')) for v in a.variants]
     print('variants:', variants)
     for name, t, heads, d in SHAPES:
