@@ -22,7 +22,7 @@ class ConvArgs(C.Structure):
                 ('n', C.c_int32), ('hin', C.c_int32), ('win', C.c_int32), ('cout', C.c_int32),
                 ('ksize', C.c_int32), ('up', C.c_int32), ('out_scale', C.c_float), ('dtype', C.c_int32),
                 ('workspace', _p), ('workspace_bytes', C.c_int64), ('stats_out', _p), ('stats_written', C.c_int32),
-                ('ev_start', _p), ('ev_stop', _p), ('gn_coef', _p), ('gn_silu', C.c_int32), ('acc_scale', C.c_float)]
+                ('ev_start', _p), ('ev_stop', _p), ('gn_coef', _p), ('gn_silu', C.c_int32), ('acc_scale', C.c_float), ('out_split2', C.c_int32)]
 
 
 # name -> argtypes (every function returns int status except the three noted below)
@@ -47,7 +47,7 @@ SIGNATURES = {
     'dts_edm_precond_out': [_p, _p, _p, _p, _i, _i, _p],
     'dts_split3_f16': [_p, _i, _p, _i, _p, _i64, _p],
     'dts_split2_f16': [_p, _i, _p, _i64, _p],
-    'dts_attention_x3': [_p, _p, _i, _i, _i, _i, _f, _p],
+    'dts_attention_x3': [_p, _p, _i, _i, _i, _i, _i, _f, _p],
     'dts_cast_from_f32': [_p, _p, _i, _i64, _p],
     'dts_cast_to_f32': [_p, _i, _p, _i64, _p],
     'dts_heun_xhat': [_p, _i, _i, _p, _i, _d, _p, _i, _i, _p],
@@ -69,7 +69,7 @@ SIGNATURES = {
 OTHER = {'dts_version': ([], _i), 'dts_conv_fuses_gn': ([C.POINTER(ConvArgs)], _i), 'dts_conv_kernel': ([C.POINTER(ConvArgs)], _i), 'dts_set_tuning': ([_i, _i], _i), 'dts_get_tuning': ([_i], _i), 'dts_last_error': ([], C.c_char_p), 'dts_gn_ws_floats': ([_i, _i], _i64)}
 
 _lib = None
-ABI_VERSION = 108              # include/dts.h DTS_ABI_VERSION this binding was written against (ConvArgs = 176 bytes)
+ABI_VERSION = 108              # include/dts.h DTS_ABI_VERSION this binding was written against (ConvArgs = 184 bytes)
 
 
 def load():
@@ -88,7 +88,7 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes, fn.restype = argt, rest
     got = lib.dts_version()
-    if got != ABI_VERSION or C.sizeof(ConvArgs) != 176:
+    if got != ABI_VERSION or C.sizeof(ConvArgs) != 184:
         raise RuntimeError(f'{LIB_PATH} has ABI version {got}, this binding needs {ABI_VERSION}: rebuild with `python -m diffusion_tts_amd.build --force`')
     _lib = lib
     return lib

@@ -99,9 +99,11 @@ class EncoderUNetModel:
         P = self.params[L.prefix]
         n, hh, ww, c = x.shape
         hn = ops.group_norm(x, 32, 1e-5, P.g, P.b, silu=False, split_out=self.x3)
-        qkv = ops.conv2d(hn, P.wqkv, P.bqkv)
-        a = ops.attention(qkv.view(n, hh * ww, 3 * c), P.heads, 1.0 / math.sqrt(c // P.heads), x3=self.x3)
-        return ops.conv2d(a.view(n, hh, ww, c), P.wproj, P.bproj, residual=x, gn_stats=True)
+        fx3 = self.x3 and ops.attention_x3_ok(hh * ww, c // P.heads)        # (see networks.EDMPrecond._block)
+        qkv = ops.conv2d(hn, P.wqkv, P.bqkv, out_split2=fx3)
+        a = ops.attention(qkv.view(n, hh * ww, 3 * c), P.heads, 1.0 / math.sqrt(c // P.heads), x3=self.x3, split_out=fx3)
+        a = ops.SplitAct(a.data.view(n, hh, ww, 3 * c), c) if fx3 else a.view(n, hh, ww, c)
+        return ops.conv2d(a, P.wproj, P.bproj, residual=x, gn_stats=True)
 
     @torch.no_grad()
     def __call__(self, x, timesteps):

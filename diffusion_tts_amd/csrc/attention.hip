@@ -58,6 +58,7 @@ struct AttP {
   float scale_log2e;
   int qblocks;                   // query blocks per (sample, head)
   int xcd_remap;                 // 1: XCD-aware block order (default); 0: plain order (A/B aid, DTS_ATT_XCD=0)
+  int out_split3;                // attention_x3_kernel: the output leaves as the split-precision conv operand image hi | lo * 2^11 | hi (f16 [n][t][3C])
 };
 
 // Block order.  The grid is 1-D over (sample*head, query block), (sample, head)-major.  Hardware deals consecutive block ids
@@ -579,10 +580,34 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const AttP p) {
     const int qrow = q0 + qt * 16 + lq;
     if (qrow < p.t) {
       const float inv = (1.0f / 64.0f) / ol[qt][0];      // (O * 2^20) / (l * 2^14) = 2^6 * O  (v carries 2^6)
-      float* orow = reinterpret_cast<float*>(p.out) + ((size_t)n * p.t + qrow) * C + head * D;
+      if (p.out_split3) {
+        // the only reader is the proj convolution of the split-precision mode: write its operand image (dts_split3_f16's arithmetic)
+        // instead of the f32 tensor + a split pass
+        f16_t* orow3 = reinterpret_cast<f16_t*>(p.out) + ((size_t)n * p.t + qrow) * 3 * C + head * D;
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-        *reinterpret_cast<float4*>(orow + dt * 16 + lg * 4) = make_float4(o[qt][dt][0] * inv, o[qt][dt][1] * inv, o[qt][dt][2] * inv, o[qt][dt][3] * inv);
+        for (int dt = 0; dt < DT; ++dt) {
+          float hi[4], lo[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x = o[qt][dt][r] * inv;
+            asm volatile("" : "+v"(x));                    // the ROUNDED product (no FMA contraction into the subtraction below): the value the f32 output holds
+            float h = f16_bits_to_f32(f32_to_f16_bits(x));
+            if (fabsf(h) < 6.103515625e-05f) h = 0.f;
+            hi[r] = h;
+            lo[r] = (x - h) * 2048.0f;
+          }
+          const uint2 h2 = make_uint2(pack2_f16(hi[0], hi[1]), pack2_f16(hi[2], hi[3])), l2 = make_uint2(pack2_f16(lo[0], lo[1]), pack2_f16(lo[2], lo[3]));
+          f16_t* d_ = orow3 + dt * 16 + lg * 4;
+          *reinterpret_cast<uint2*>(d_) = h2;
+          *reinterpret_cast<uint2*>(d_ + C) = l2;
+          *reinterpret_cast<uint2*>(d_ + 2 * C) = h2;
+        }
+      } else {
+        float* orow = reinterpret_cast<float*>(p.out) + ((size_t)n * p.t + qrow) * C + head * D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+          *reinterpret_cast<float4*>(orow + dt * 16 + lg * 4) = make_float4(o[qt][dt][0] * inv, o[qt][dt][1] * inv, o[qt][dt][2] * inv, o[qt][dt][3] * inv);
+      }
     }
   }
 }
@@ -760,11 +785,11 @@ int att32(const AttP& p, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int dts_attention_x3(const void* qkv_split, float* out, int n, int t, int heads, int d, float scale, dts_stream s) {
+extern "C" int dts_attention_x3(const void* qkv_split, void* out, int out_split3, int n, int t, int heads, int d, float scale, dts_stream s) {
   DTS_CHECK_ARG(qkv_split && out, "dts_attention_x3: null pointer");
   DTS_CHECK_ARG(n > 0 && t > 0 && heads > 0, "dts_attention_x3: bad shape");
   DTS_CHECK_ARG(d == 64, "dts_attention_x3: head dim %d unsupported (64; other sizes take dts_attention in DTS_F32)", d);
-  AttP p{(const char*)qkv_split, (char*)out, n, t, heads, d, scale * 1.4426950408889634f, 0, 1};
+  AttP p{(const char*)qkv_split, (char*)out, n, t, heads, d, scale * 1.4426950408889634f, 0, 1, out_split3 ? 1 : 0};
   const size_t lds = (size_t)2 * 64 * (2 * 64 * 2 + 32);
   // two query tiles per wave once the sequence is long enough to keep >= 2 blocks per CU in the grid (the rule of the 16-bit kernel)
   if (t >= 256 && (long long)((t + 127) / 128) * n * heads >= 512) return launch_att(attention_x3_kernel<2>, p, lds, to_stream(s), 128);
@@ -776,7 +801,7 @@ extern "C" int dts_attention(const void* qkv, void* out, int dtype, int n, int t
   DTS_CHECK_ARG(n > 0 && t > 0 && heads > 0, "dts_attention: bad shape");
   DTS_CHECK_ARG(d == 64 || d == 128 || d == 256 || (d == 512 && dtype != DTS_F32),
                 "dts_attention: head dim %d unsupported (64/128/256; 512 in the 16-bit types)", d);
-  AttP p{(const char*)qkv, (char*)out, n, t, heads, d, scale * 1.4426950408889634f, 0, 1};
+  AttP p{(const char*)qkv, (char*)out, n, t, heads, d, scale * 1.4426950408889634f, 0, 1, 0};
   hipStream_t st = to_stream(s);
   switch (dtype) {
     case DTS_F32: return att32(p, st);

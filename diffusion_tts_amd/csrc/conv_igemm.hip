@@ -24,7 +24,7 @@
 #include <hip/hip_ext.h>
 #include <type_traits>
 
-static_assert(sizeof(dts_conv_args) == 176, "dts_conv_args layout changed: bump DTS_ABI_VERSION and update the bindings (_lib.py ConvArgs)");
+static_assert(sizeof(dts_conv_args) == 184, "dts_conv_args layout changed: bump DTS_ABI_VERSION and update the bindings (_lib.py ConvArgs)");
 
 namespace {
 
@@ -55,6 +55,8 @@ struct ConvP {
   float* stats;    // optional [ceil(P/64)][cout][2]: per 64-pixel strip (sum, sumsq) of the stored outputs (GroupNorm input)
   float out_scale;
   float acc_scale;         // the accumulators are scaled by this before anything is added (split-precision mode: the packed weights carry 2^k)
+  int out_split2;          // split-precision mode, f32 epilogue only: the output leaves as the f16 image hi(cout) | lo(cout) of v * 2^6 per pixel
+                           // (dts_split2_f16's arithmetic: what dts_attention_x3 reads) instead of as f32 values
   int w_shift, hw_shift;   // log2(wout), log2(hout*wout) when both are powers of two, else -1 (pixel coordinates by division)
   const float* gn_coef;    // optional [n][cin][2] (a, b): GroupNorm of the INPUT applied on the staged halo tile (conv_pp_kernel only)
   int gn_silu;
@@ -504,7 +506,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
       const V4 pk = Vec4<T>::pack(v);
       if constexpr (VIA_LDS)
         *reinterpret_cast<V4*>(smem + (wn * 16 * NT + nt * 16 + lrow) * ROWP + (wm * 16 * MT + mt * 16 + lq * 4) * 2) = pk;
-      else
+      else if (sizeof(T) == 4 && kp.out_split2) {
+        // the qkv projection of the split-precision mode: its only reader is the split-precision attention, so the f32 tensor and the
+        // separate split pass (4 B written + 4 B read per element) are skipped
+        float hi[4], lo[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float y = v[r] * 64.0f;
+          hi[r] = f16_bits_to_f32(f32_to_f16_bits(y));
+          lo[r] = y - hi[r];
+        }
+        f16_t* orow = reinterpret_cast<f16_t*>(kp.out) + (size_t)ppv[nt] * 2 * p_cout + co;
+        *reinterpret_cast<uint2*>(orow) = make_uint2(pack2_f16(hi[0], hi[1]), pack2_f16(hi[2], hi[3]));
+        *reinterpret_cast<uint2*>(orow + p_cout) = make_uint2(pack2_f16(lo[0], lo[1]), pack2_f16(lo[2], lo[3]));
+      } else
         *reinterpret_cast<V4*>(out + (size_t)ppv[nt] * p_cout + co) = pk;
       if (want_stats) {                                // moments of the values as stored (rounded to T)
         float f[4];
@@ -1407,7 +1422,7 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, C
   // which for many-pixel layers at a small batch costs more than the shorter K loop saves.
   const int slots = 512;                                     // 256 CUs x 2 resident blocks
   int splits = 1;
-  if (ws != nullptr && nblk < (slots * 3) / 4 && nk >= 16) {
+  if (ws != nullptr && nblk < (slots * 3) / 4 && nk >= 16 && !p.out_split2) {      // (the split-image output is written by the conv epilogue only)
     int smax = 8;
     if (smax > nk / 8) smax = nk / 8;
     while (smax > 1 && (long long)smax * p.P * p.cout * 4 > ws_bytes) --smax;
@@ -1430,7 +1445,7 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, C
     const int forced = dts_knob_get(DTS_KNOB_CONV_SPLITS);    // DTS_CONV_SPLITS: tuning aid, as in the ping-pong launcher
     // (the reduce pass is instantiated for 2..8 slabs: a larger forced value is clamped here, as in the ping-pong launcher, instead of
     // launching the conv kernel and then failing in launch_reduce with the output never produced)
-    const int f8 = forced > 8 ? 8 : forced;
+    const int f8 = (forced > 8 ? 8 : forced) * (p.out_split2 ? 0 : 1);
     if (f8 > 0 && ws != nullptr && nk >= 2 * f8 && (long long)f8 * p.P * p.cout * 4 <= ws_bytes) splits = f8;
   }
   q.ks_per_split = (nk + splits - 1) / splits;
@@ -1495,7 +1510,7 @@ int launch_conv_pp(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes
     const int nk = p.taps * (p.cin / BKE);
     int splits = 1;
     const int forced = dts_knob_get(DTS_KNOB_CONV_SPLITS);
-    if (ws != nullptr && nk >= 16) {
+    if (ws != nullptr && nk >= 16 && !p.out_split2) {
       if (forced > 0) splits = forced;
       else if (nblk < 192) {
         // One resident block per CU.  Splitting K fills idle CUs but pays a second pass over `splits` f32 slabs of P x cout, which for
@@ -1717,6 +1732,8 @@ extern "C" int dts_conv2d(dts_conv_args* a, dts_stream s) {
   const long long P = (long long)p.n * p.hout * p.wout;
   DTS_CHECK_ARG(P < (1ll << 30), "dts_conv2d: too many pixels");
   p.P = (int)P; p.out_scale = a->out_scale; p.acc_scale = a->acc_scale == 0.f ? 1.f : a->acc_scale; p.n_ct = p.n_pt = 0;
+  p.out_split2 = a->out_split2;
+  DTS_CHECK_ARG(!a->out_split2 || (a->dtype == DTS_F16X3 && a->stats_out == nullptr), "dts_conv2d: out_split2 is the split-precision mode's, without strip statistics");
   p.splits = 1; p.ks_per_split = 0; p.partial = nullptr;
   p.w_shift = p.hw_shift = -1;
   {

@@ -197,9 +197,13 @@ class EDMPrecond:
         if b.heads:
             n, hh, ww, c = x.shape
             hn = ops.group_norm(x, G(c), self.eps, P.g2, P.b2, silu=False, split_out=self.x3)
-            qkv = ops.conv2d(hn, P.wqkv, P.bqkv)
-            a = ops.attention(qkv.view(n, hh * ww, 3 * c), b.heads, 1.0 / math.sqrt(c // b.heads), x3=self.x3)
-            x = ops.conv2d(a.view(n, hh, ww, c), P.wproj, P.bproj, residual=x, out_scale=self.skip_scale, gn_stats=True)
+            # split-precision mode: qkv leaves the projection as the attention's operand image and the attention's result as the proj
+            # convolution's (no f32 tensors and no split passes in between) wherever the split-precision attention kernel runs
+            fx3 = self.x3 and ops.attention_x3_ok(hh * ww, c // b.heads)
+            qkv = ops.conv2d(hn, P.wqkv, P.bqkv, out_split2=fx3)
+            a = ops.attention(qkv.view(n, hh * ww, 3 * c), b.heads, 1.0 / math.sqrt(c // b.heads), x3=self.x3, split_out=fx3)
+            a = ops.SplitAct(a.data.view(n, hh, ww, 3 * c), c) if fx3 else a.view(n, hh, ww, c)
+            x = ops.conv2d(a, P.wproj, P.bproj, residual=x, out_scale=self.skip_scale, gn_stats=True)
         return x
 
     @torch.no_grad()

@@ -6,6 +6,7 @@ Activation tensors are NHWC: shape [n, h, w, c], contiguous, dtype float32 / bfl
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -40,6 +41,18 @@ class X3Weight:
 
     def numel(self):
         return self.packed.numel()
+
+
+class SplitQKV:
+    """The qkv projection's result in the split-precision attention's operand form: `data` float16 [n,t,6*C] = hi(3C) | lo(3C) of the
+    values * 2^6 (dts_split2_f16's image, written by conv2d(..., out_split2=True)); `shape` is the logical [n, h, w, 3*C]."""
+
+    def __init__(self, data, shape):
+        self.data, self.shape = data, tuple(shape)
+        self.device, self.dtype = data.device, torch.float32
+
+    def view(self, n, t, c3):
+        return SplitQKV(self.data.view(n, t, 2 * c3), (n, t, c3))
 
 
 class SplitAct:
@@ -177,7 +190,7 @@ def conv_fuses_gn(x1, w, *, x2=None, up=False):
 
 
 def conv2d(x1, w, bias=None, *, x2=None, bias_nc=None, residual=None, up=False, out_scale=1.0, out=None, gn_stats=False,
-           timing_events=None, gn_coef=None, gn_silu=True):
+           timing_events=None, gn_coef=None, gn_silu=True, out_split2=False):
     """timing_events=(start, stop): raw hipEvent_t handles attached to the conv kernel's own dispatch (measurement only).
     gn_stats=True: the epilogue also emits the GroupNorm moments of the output (per 64-pixel strip and channel); they
     ride on the returned tensor as `out._gn_stats` (None when the launch could not produce them) and are consumed by
@@ -193,9 +206,13 @@ def conv2d(x1, w, bias=None, *, x2=None, bias_nc=None, residual=None, up=False, 
         raise ValueError('conv2d: a split-precision weight takes float32 activations (and no fused input GroupNorm)')
     if isinstance(x1, SplitAct) and (not x3 or x2 is not None):
         raise ValueError('conv2d: a split activation feeds a split-precision weight, alone')
-    if out is None:
+    out_split2 = bool(out_split2) and x3 and not gn_stats       # (split-precision mode only: the qkv projection feeding attention(x3=True))
+    if out_split2:
+        out = torch.empty((n, ho, wo, 2 * cout), dtype=torch.float16, device=x1.device)
+    elif out is None:
         out = torch.empty((n, ho, wo, cout), dtype=x1.dtype, device=x1.device)
     a = L.ConvArgs()
+    a.out_split2 = int(out_split2)
     dt_in = x1.dtype
     if x3:      # the conv reads the f16 split image hi | lo | hi of concat(x1, x2); epilogue operands and output stay float32
         xs = x1.data if isinstance(x1, SplitAct) else split3_f16(x1, x2)
@@ -210,7 +227,7 @@ def conv2d(x1, w, bias=None, *, x2=None, bias_nc=None, residual=None, up=False, 
     a.residual = _ptr(residual, 'residual', x1.dtype)
     if residual is not None and tuple(residual.shape) != (n, ho, wo, cout):
         raise ValueError(f'conv2d: residual shape {tuple(residual.shape)} != {(n, ho, wo, cout)}')
-    a.out = _ptr(out, 'out', x1.dtype)
+    a.out = _ptr(out, 'out', torch.float16 if out_split2 else x1.dtype)
     a.n, a.hin, a.win, a.cout, a.ksize = n, hin, win, cout, kh
     a.up, a.out_scale, a.dtype = int(up), float(out_scale), (L.DTS_F16X3 if x3 else dt_code(x1.dtype))
     ws = _conv_workspace(x1.device)
@@ -226,6 +243,8 @@ def conv2d(x1, w, bias=None, *, x2=None, bias_nc=None, residual=None, up=False, 
             raise ValueError(f'conv2d: gn_coef shape {tuple(gn_coef.shape)} != {(n, c1 + c2, 2)}')
         a.gn_coef, a.gn_silu = _ptr(gn_coef, 'gn_coef', torch.float32), int(gn_silu)
     _call('dts_conv2d', C.byref(a))
+    if out_split2:
+        return SplitQKV(out, (n, ho, wo, cout))
     out._gn_stats = st if (st is not None and a.stats_written) else None
     return out
 
@@ -351,21 +370,37 @@ def resample2x(x, up):
 
 
 # ---- attention ----------------------------------------------------------------------------------
-def attention(qkv, heads, scale, x3=False):
-    """qkv [n, t, 3*heads*d] (q|k|v blocks) -> [n, t, heads*d].  x3 (split-precision mode, float32 qkv, head dim 64): Q.K^T and P.V on the
-    16-bit matrix cores with hi/lo operand pairs (dts_attention_x3) instead of the f32 matrix instruction; same accuracy."""
+def attention(qkv, heads, scale, x3=False, split_out=False):
+    """qkv [n, t, 3*heads*d] (q|k|v blocks) -> [n, t, heads*d].  x3 (split-precision mode, float32 qkv or a SplitQKV, head dim 64): Q.K^T and
+    P.V on the 16-bit matrix cores with hi/lo operand pairs (dts_attention_x3) instead of the f32 matrix instruction; same accuracy.
+    split_out (with x3): the result leaves as the operand image of the proj convolution (SplitAct [n, t, 1, C])."""
     n, t, c3 = qkv.shape
     c = c3 // 3
     d = c // heads
-    out = torch.empty((n, t, c), dtype=qkv.dtype, device=qkv.device)
+    pre = isinstance(qkv, SplitQKV)
     # (short sequences stay on the f32 kernel: at T = 64 the split pass alone costs what that launch does -- tools/att_bench.py --x3)
-    if x3 and d == 64 and t >= 128 and qkv.dtype == torch.float32:
-        sp = torch.empty((n, t, 2 * c3), dtype=torch.float16, device=qkv.device)
-        _call('dts_split2_f16', _ptr(qkv, 'qkv', torch.float32), c3, _ptr(sp), n * t)
-        _call('dts_attention_x3', _ptr(sp), _ptr(out), n, t, heads, d, float(scale))
+    if pre or (x3 and d == 64 and t >= 128 and qkv.dtype == torch.float32):
+        if pre:
+            sp = qkv.data
+        else:
+            sp = torch.empty((n, t, 2 * c3), dtype=torch.float16, device=qkv.device)
+            _call('dts_split2_f16', _ptr(qkv, 'qkv', torch.float32), c3, _ptr(sp), n * t)
+        if split_out:
+            out = torch.empty((n, t, 3 * c), dtype=torch.float16, device=qkv.device)
+            _call('dts_attention_x3', _ptr(sp), _ptr(out), 1, n, t, heads, d, float(scale))
+            return SplitAct(out.view(n, t, 1, 3 * c), c)
+        out = torch.empty((n, t, c), dtype=torch.float32, device=qkv.device)
+        _call('dts_attention_x3', _ptr(sp), _ptr(out), 0, n, t, heads, d, float(scale))
         return out
+    out = torch.empty((n, t, c), dtype=qkv.dtype, device=qkv.device)
     _call('dts_attention', _ptr(qkv), _ptr(out), dt_code(qkv.dtype), n, t, heads, d, float(scale))
     return out
+
+
+def attention_x3_ok(t, d):
+    """whether attention(..., x3=True) takes the split-precision kernel for this sequence length / head dim (so that the qkv projection may
+    write its operand image directly and the proj convolution may read one)"""
+    return d == 64 and t >= 128 and os.environ.get('DTS_X3_FUSE_IMAGES', '1') != '0'     # (0: A/B aid -- f32 tensors + split passes)
 
 
 # ---- embedding / preconditioning ----------------------------------------------------------------

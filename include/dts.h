@@ -93,6 +93,8 @@ typedef struct dts_conv_args {
   int32_t gn_silu;                /* 1: act = SiLU, 0: identity */
   float acc_scale;                /* DTS_F16X3 only (0 = 1): out = (conv * acc_scale + bias + bias_nc + residual) * out_scale; undoes the power of
                                      two the packed split-precision weights carry */
+  int32_t out_split2;             /* DTS_F16X3 only: 1 = `out` is f16 [n][hout][wout][2*cout] = hi(cout) | lo(cout) of the result * 2^6 per pixel (the
+                                     image dts_split2_f16 would make of it: the qkv projection feeding dts_attention_x3) instead of f32 [..][cout] */
 } dts_conv_args;
 /* 1 if dts_conv2d would apply a->gn_coef inside the conv for this shape / dtype (3x3, cout % 192 == 0, 16-bit, square power-of-two
  * images >= 16, whole 256-pixel tiles, no fused upsample), else 0: the caller then runs dts_gn_apply first. */
@@ -143,9 +145,10 @@ int dts_resample2x(const void* x, void* out, int dtype, int n, int h, int w, int
  * out [n][t][heads*d]; softmax(q.k * scale) in f32. d in {64,128,256} (and 512 in the 16-bit types: the SD VAE's mid block); any t >= 1. */
 int dts_attention(const void* qkv, void* out, int dtype, int n, int t, int heads, int d, float scale, dts_stream s);
 /* the same attention in the split-precision mode (DTS_F16X3; d = 64): qkv_split = dts_split2_f16 of the f32 qkv tensor, f16 [n][t][6*heads*d] =
- * hi(3C) | lo(3C) per token; out f32 [n][t][heads*d].  Q.K^T and P.V on the 16-bit matrix cores with hi/lo operand pairs (the lo*lo term,
+ * hi(3C) | lo(3C) per token (also what dts_conv2d writes with out_split2); out f32 [n][t][heads*d], or with out_split3 = 1 the f16 operand
+ * image [n][t][3*heads*d] (hi | lo * 2^11 | hi, dts_split3_f16's arithmetic) the proj convolution reads.  Q.K^T and P.V on the 16-bit matrix cores with hi/lo operand pairs (the lo*lo term,
  * 2^-22, dropped), softmax in f32: the f32 kernel's accuracy without the f32 matrix instruction's 1/16 rate. */
-int dts_attention_x3(const void* qkv_split, float* out, int n, int t, int heads, int d, float scale, dts_stream s);
+int dts_attention_x3(const void* qkv_split, void* out, int out_split3, int n, int t, int heads, int d, float scale, dts_stream s);
 
 /* ---- K7/K8: embedding MLP pieces and EDM preconditioning (networks.py:200-206,437-447,654-668) ---- */
 /* y[m][n] = act_out( act_in(x[m][:]) . w[n][:] + bias[n] (+ y[m][n] if accumulate) ); all f32; act: 0 none, 1 SiLU */

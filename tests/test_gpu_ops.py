@@ -552,13 +552,33 @@ def test_attention_split_precision(ops, shape, spread):
         out = torch.empty((n, t, c), dtype=torch.float32, device=DEV)
         st = torch.cuda.current_stream().cuda_stream
         _lib.check(_lib.load().dts_split2_f16(x.data_ptr(), 3 * c, sp.data_ptr(), n * t, st), 'dts_split2_f16')
-        _lib.check(_lib.load().dts_attention_x3(sp.data_ptr(), out.data_ptr(), n, t, heads, d, 1.0 / math.sqrt(d), st), 'dts_attention_x3')
+        _lib.check(_lib.load().dts_attention_x3(sp.data_ptr(), out.data_ptr(), 0, n, t, heads, d, 1.0 / math.sqrt(d), st), 'dts_attention_x3')
         got3 = out.double().cpu()
     got32 = ops.attention(x, heads, 1.0 / math.sqrt(d)).double().cpu()
     scale = float(ref.abs().max())
     e3, e32 = float((got3 - ref).abs().max()) / scale, float((got32 - ref).abs().max()) / scale
     print(f'split-precision attention n={n} t={t} heads={heads} spread={spread}: rel err {e3:.2e} (f32 kernel {e32:.2e})')
     assert e3 < max(1e-6, 1.25 * e32), (e3, e32)      # (measured: 0.4x ... 0.7x the f32 kernel's error everywhere; sharp softmaxes amplify both)
+
+
+def test_split_precision_attention_block_without_f32_tensors(ops):
+    """The attention block of the split-precision mode passes operand images, not f32 tensors: the qkv projection writes the attention's
+    image (conv2d(out_split2=True) == dts_split2_f16 of its f32 result, bit for bit) and the attention writes the proj convolution's
+    (attention(split_out=True) == dts_split3_f16 of its f32 result, bit for bit)."""
+    gen = g(73)
+    n, hh, ww, c, heads = 2, 16, 16, 128, 2
+    x = to_nhwc(ops, torch.randn(n, c, hh, ww, generator=gen), torch.float32)
+    wq = ops.pack_conv_weight((torch.randn(3 * c, c, 1, 1, generator=gen) / math.sqrt(c)).to(DEV), ops.F16X3)
+    bq = torch.randn(3 * c, generator=gen).to(DEV)
+    plain = ops.conv2d(x, wq, bq)
+    fused = ops.conv2d(x, wq, bq, out_split2=True)
+    assert isinstance(fused, ops.SplitQKV) and tuple(fused.shape) == tuple(plain.shape)
+    sp = torch.empty((n, hh * ww, 6 * c), dtype=torch.float16, device=DEV)
+    ops._call('dts_split2_f16', plain.data_ptr(), 3 * c, sp.data_ptr(), n * hh * ww)
+    assert torch.equal(fused.data.view(n, hh * ww, 6 * c), sp)
+    a32 = ops.attention(plain.view(n, hh * ww, 3 * c), heads, 0.125, x3=True)
+    a3 = ops.attention(fused.view(n, hh * ww, 3 * c), heads, 0.125, x3=True, split_out=True)
+    assert isinstance(a3, ops.SplitAct) and torch.equal(a3.data.view(n, hh * ww, 3 * c), ops.split3_f16(a32.view(n, hh * ww, 1, c)).view(n, hh * ww, 3 * c))
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
