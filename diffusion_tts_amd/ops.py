@@ -54,6 +54,12 @@ class SplitQKV:
     def view(self, n, t, c3):
         return SplitQKV(self.data.view(n, t, 2 * c3), (n, t, c3))
 
+    def numel(self):                     # logical elements; each is an f16 pair = 4 bytes, like the f32 value it stands for
+        return self.data.numel() // 2
+
+    def element_size(self):
+        return 4
+
 
 class SplitAct:
     """An activation already in the split-precision operand form: `data` float16 [n,h,w,3*C] = hi | lo * 2^11 | hi (dts_split3_f16 /
