@@ -16,7 +16,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, cases=((8, 1), (7, 2), (64, 1), (3, 1))):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
@@ -24,7 +24,7 @@ def _worker(rank, world, port, q):
         sh = CandidateShards()
         assert (sh.rank, sh.world) == (rank, world)
         out = {}
-        for N, B in ((8, 1), (7, 2), (64, 1), (3, 1)):
+        for N, B in cases:
             spans = [sh.span(N, r) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == N and all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             g = torch.Generator().manual_seed(100 + N)                  # replicated "host RNG"
@@ -61,6 +61,25 @@ def test_candidate_sharding_world2_gloo():
         assert p.exitcode == 0
     res = dict(res)
     assert res[0] == res[1]                                              # identical survivor on every rank
+
+
+def test_candidate_sharding_world8_gloo():
+    """The rank count of BASELINE config 3 (N = 64 candidates over 8 GPUs, 8 each), rehearsed over gloo on the CPU: contiguous spans that
+    cover the candidates, ONE reward collective per decision, the same first-max survivor on all 8 ranks, the rejection winner broadcast
+    from whichever rank owns it; also an uneven split (13 candidates) and a batch of two images."""
+    world = 8
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, ((64, 1), (8, 1), (13, 1), (16, 2)))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res = dict(res)
+    assert len(res) == world and all(res[r] == res[0] for r in range(world))
 
 
 def test_single_process_is_a_noop():
