@@ -529,8 +529,8 @@ def test_attention(ops, dtype, shape):
     assert rel_err(out, ref) < (3e-5 if dtype == torch.float32 else TOL[dtype])
 
 
-@pytest.mark.parametrize('shape', [(2, 64, 2), (1, 256, 3), (2, 65, 2), (3, 1, 1), (1, 1024, 2), (2, 130, 12)])
-@pytest.mark.parametrize('spread', [1.0, 4.0, 0.01])
+@pytest.mark.parametrize('shape,spread', [(sh, sp) for sp in (1.0, 4.0, 0.01) for sh in [(2, 64, 2), (1, 256, 3), (2, 65, 2), (3, 1, 1), (1, 1024, 2), (2, 130, 12)]] +
+                         [((16, 1024, 4), 1.0), ((32, 300, 6), 1.0)])      # the last two: grids large enough for two query tiles per wave (full and ragged)
 def test_attention_split_precision(ops, shape, spread):
     """ops.attention(..., x3=True) (dts_split2_f16 + dts_attention_x3, head dim 64): Q.K^T and P.V on the 16-bit matrix cores with hi/lo
     operand pairs.  Against an f64 reference it must be as close as the f32 kernel (not f16's 2^-11): full, ragged and one-token
