@@ -88,8 +88,8 @@ def test_candidate_batch_64_properties(adm):
     assert (D8 - D[56:64]).abs().max().item() < 2e-2 * D.abs().max().item()
 
 
-def _full_run(cfg, sd, method, params, latents, labels, seed):
-    """Same search on the GPU (f32 = parity mode) and through the CPU oracle."""
+def _full_run(cfg, sd, method, params, latents, labels, seed, modes=(torch.float32,)):
+    """Same search on the GPU (in each parity mode of `modes`) and through the CPU oracle (once).  Returns (oracle, [gpu result per mode], evals)."""
     from diffusion_tts_amd import sampler as sm, scorers as S
     from diffusion_tts_amd.hashing import seed0_scale
     from diffusion_tts_amd.networks import EDMPrecond
@@ -98,12 +98,14 @@ def _full_run(cfg, sd, method, params, latents, labels, seed):
     onet = oracle_net(cfg, sd)
     o = osamp.search(onet, latents, labels, method=method, params=dict(scorer=oscore.BrightnessOracle(), **params),
                      scale_fn=seed0_scale, **kw)
-    net = EDMPrecond(cfg, sd, device=DEV, dtype=torch.float32)
-    h = sm.generate_image_grid(net, None, latents, labels, gridw=1, gridh=1, device=torch.device(DEV),
-                               sampling_method={'naive': sm.SamplingMethod.NAIVE, 'rejection': sm.SamplingMethod.REJECTION_SAMPLING}[method],
-                               sampling_params=dict(scorer=S.BrightnessScorer(), **params), scale_fn=seed0_scale,
-                               compute_dtype=torch.float32, verbose=False, **kw)
-    return o, h, onet.evals
+    hs = []
+    for dt in modes:
+        net = EDMPrecond(cfg, sd, device=DEV, dtype=dt)
+        hs.append(sm.generate_image_grid(net, None, latents, labels, gridw=1, gridh=1, device=torch.device(DEV),
+                                         sampling_method={'naive': sm.SamplingMethod.NAIVE, 'rejection': sm.SamplingMethod.REJECTION_SAMPLING}[method],
+                                         sampling_params=dict(scorer=S.BrightnessScorer(), **params), scale_fn=seed0_scale,
+                                         compute_dtype=dt, verbose=False, **kw))
+    return o, hs, onet.evals
 
 
 def test_baseline_config1_ddpmpp_naive_full_trajectory():
@@ -114,10 +116,13 @@ def test_baseline_config1_ddpmpp_naive_full_trajectory():
     g = torch.Generator().manual_seed(0)
     latents = torch.randn(1, 3, 32, 32, generator=g)
     labels = torch.eye(10)[torch.tensor([3])]
-    o, h, evals = _full_run(cfg, sd, 'naive', {}, latents, labels, seed=0)
-    assert evals == 35 and h['net_rows'] == 35
-    assert (o['x'] - h['x'].cpu()).abs().max().item() < 1e-3
-    assert (o['image'].int() - h['image'].int()).abs().max().item() <= 1
+    o, hs, evals = _full_run(cfg, sd, 'naive', {}, latents, labels, seed=0, modes=(torch.float32, X3))
+    for h, mode in zip(hs, ('f32', 'f16x3')):          # both parity modes (split precision: bias_nc convs, head-dim-256 attention on the f32 kernel)
+        assert evals == 35 and h['net_rows'] == 35
+        err = (o['x'] - h['x'].cpu()).abs().max().item()
+        print(f'config 1 (DDPM++-32 naive, 35 evaluations), {mode}: max |x - x_oracle| = {err:.2e}')
+        assert err < 1e-3
+        assert (o['image'].int() - h['image'].int()).abs().max().item() <= 1
 
 
 def test_baseline_config2_ddpmpp_rejection_full_trajectories():
@@ -128,13 +133,14 @@ def test_baseline_config2_ddpmpp_rejection_full_trajectories():
     g = torch.Generator().manual_seed(1)
     latents = torch.randn(1, 3, 32, 32, generator=g)
     labels = torch.eye(10)[torch.tensor([7])]
-    o, h, evals = _full_run(cfg, sd, 'rejection', dict(N=16), latents, labels, seed=0)
-    assert evals == 16 * 35 and h['net_rows'] == 16 * 35
-    assert (torch.cat([r.flatten() for r in o['rewards']]) - torch.cat([r.flatten() for r in h['rewards']])).abs().max().item() < 5e-5
-    # rewards are [B, N] here: decide over the candidate axis
-    same, _ = check_decisions([r.t() for r in o['rewards']], o['selected'], h['selected'], 'config 2 rejection')
-    assert same
-    assert (o['x'] - h['x'].cpu()).abs().max().item() < 1e-3
+    o, hs, evals = _full_run(cfg, sd, 'rejection', dict(N=16), latents, labels, seed=0, modes=(torch.float32, X3))
+    for h, mode in zip(hs, ('f32', 'f16x3')):
+        assert evals == 16 * 35 and h['net_rows'] == 16 * 35
+        assert (torch.cat([r.flatten() for r in o['rewards']]) - torch.cat([r.flatten() for r in h['rewards']])).abs().max().item() < 5e-5
+        # rewards are [B, N] here: decide over the candidate axis
+        same, _ = check_decisions([r.t() for r in o['rewards']], o['selected'], h['selected'], f'config 2 rejection ({mode})')
+        assert same
+        assert (o['x'] - h['x'].cpu()).abs().max().item() < 1e-3
 
 
 def test_baseline_config3_adm64_eps_greedy_imagenet_scorer_reduced(adm):
