@@ -337,18 +337,22 @@ def test_config5_mcts_full_size_matches_oracle(adm):
     kw = dict(seed=1, num_steps=3, S_churn=40, S_min=0.05, S_max=50, S_noise=1.003)
     np.random.seed(0)
     o = osamp.search(onet, latents, labels, method='mcts', params=dict(scorer=oscorer, **params), scale_fn=seed0_scale, **kw)
-    np.random.seed(0)
-    h = sm.generate_image_grid(net, None, latents, labels, gridw=1, gridh=1, device=torch.device(DEV),
-                               sampling_method=sm.SamplingMethod.MCTS, sampling_params=dict(scorer=scorer, **params),
-                               scale_fn=seed0_scale, compute_dtype=torch.float32, verbose=False, **kw)
-    assert h['net_rows'] == onet.evals
-    assert len(o['rewards']) == len(h['rewards']) == 3 and len(o['selected']) == len(h['selected']) == 3
-    errs = [float((ro - rh.cpu()).abs().max()) for ro, rh in zip(o['rewards'], h['rewards'])]
-    print(f'config 5 (MCTS N=4 S=16, 3 steps), f32: reward errs {errs}, chosen children {[int(s) for s in h["selected"]]} '
-          f'(oracle {[int(s) for s in o["selected"]]}), rows {h["net_rows"]}')
-    assert max(errs) < 5e-5
-    assert [int(s) for s in o['selected']] == [int(s) for s in h['selected']]
-    assert (o['x'] - h['x'].cpu()).abs().max().item() < 1e-3
+    for mode, dt in (('f32', torch.float32), ('f16x3', X3)):        # both parity modes against the one oracle run
+        if dt is not torch.float32:
+            del net, scorer
+            net, scorer, _, _ = _adm_and_scorers(adm, dt)
+        np.random.seed(0)
+        h = sm.generate_image_grid(net, None, latents, labels, gridw=1, gridh=1, device=torch.device(DEV),
+                                   sampling_method=sm.SamplingMethod.MCTS, sampling_params=dict(scorer=scorer, **params),
+                                   scale_fn=seed0_scale, compute_dtype=dt, verbose=False, **kw)
+        assert h['net_rows'] == onet.evals
+        assert len(o['rewards']) == len(h['rewards']) == 3 and len(o['selected']) == len(h['selected']) == 3
+        errs = [float((ro - rh.cpu()).abs().max()) for ro, rh in zip(o['rewards'], h['rewards'])]
+        print(f'config 5 (MCTS N=4 S=16, 3 steps), {mode}: reward errs {errs}, chosen children {[int(s) for s in h["selected"]]} '
+              f'(oracle {[int(s) for s in o["selected"]]}), rows {h["net_rows"]}')
+        assert max(errs) < 5e-5
+        assert [int(s) for s in o['selected']] == [int(s) for s in h['selected']]
+        assert (o['x'] - h['x'].cpu()).abs().max().item() < 1e-3
 
 
 def test_config5_mcts_s256_bf16_smoke(adm):
