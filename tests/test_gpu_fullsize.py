@@ -243,6 +243,12 @@ def test_config3_full_candidate_batch_n64_one_iteration_matches_oracle(adm):
     assert gap > 2 * err, f'top-2 gap {gap:.2e} is not above the observed fp32 error {err:.2e}: pick another seed'
     assert int(rew_h.argmax()) == best_o
     del net, scorer
+    n3, s3, _, _ = _adm_and_scorers(adm, X3)                        # the second parity mode: split precision on the 16-bit matrix cores
+    _, x0_3, r3 = gpu(n3, s3)
+    e3 = (r3 - rew_o).abs().max().item()
+    print(f'config 3, N=64, f16x3: max reward err {e3:.2e}, argmax {int(r3.argmax())} (oracle {best_o}), max |x0 - x0_oracle| {(x0_3 - x0_o).abs().max().item():.2e}')
+    assert e3 < 5e-8 and gap > 2 * e3 and int(r3.argmax()) == best_o and (x0_3 - x0_o).abs().max().item() < 1e-3
+    del n3, s3
     for dt in (torch.float16, torch.bfloat16):                      # throughput modes: same inputs; agreement is reported, bounded loosely
         n16, s16, _, _ = _adm_and_scorers(adm, dt)
         _, _, r16 = gpu(n16, s16)
