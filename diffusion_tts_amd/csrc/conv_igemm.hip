@@ -1622,8 +1622,8 @@ int conv_dispatch(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes,
   const int g_tile_override = dts_knob_get(DTS_KNOB_CONV_TILE);     // DTS_CONV_TILE=64|128|192 (tuning aid; only honoured when it divides cout)
   int tile = (p.cout % 192 == 0) ? 192 : (p.cout % 128 == 0 ? 128 : 64);    // measured: tools/conv_bench.py
   // f32 (parity mode): the 192-cout tile spilled until round 4 (its epilogue held 96 residual registers beside 96 accumulators; the residual
-  // slices now come two at a time: 204-220 VGPRs, no scratch).  DTS_XP_F32_TILE192=0 restores the smaller tile (A/B aid).
-  static const bool f32_192 = !(getenv("DTS_XP_F32_TILE192") && atoi(getenv("DTS_XP_F32_TILE192")) == 0);
+  // slices now come two at a time: 204-220 VGPRs, no scratch).  DTS_F32_TILE192=0 restores the smaller tile (A/B aid).
+  static const bool f32_192 = !(getenv("DTS_F32_TILE192") && atoi(getenv("DTS_F32_TILE192")) == 0);
   if (std::is_same<T, float>::value && tile == 192 && !f32_192) tile = (p.cout % 128 == 0) ? 128 : 64;
   const int pp = conv_pick_pp(std::is_same<T, float>::value, p);
   if constexpr (!std::is_same<T, OT>::value) {       // split-precision mode: the two shipped ping-pong forms and the implicit-GEMM forms, no knob variants
