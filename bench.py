@@ -45,7 +45,9 @@ def torch_dtype(name):
     return {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32, 'f16x3': ops.F16X3}[name]
 GFLOP_PER_EVAL = {'adm64': 219.33, 'ddpmpp32': 42.38}             # BASELINE.md section 2 / SURVEY.md 8(d)
 CLS_GFLOP_PER_IMG = 38.16
-TRAFFIC_PROFILE = 'profiles/r04_hbm_traffic_pmc.json'             # written by tools/pmc_traffic.py from the rocprofv3 --pmc passes
+# written by tools/final_run.sh at HEAD: tools/pmc_traffic.py from the rocprofv3 --pmc passes, tools/rocprof_dominant.py from the --kernel-trace --stats pass
+TRAFFIC_PROFILE = {'f16x3': 'profiles/r05_hbm_traffic_pmc_f16x3.json', 'bf16': 'profiles/r05_hbm_traffic_pmc_bf16.json'}
+ROCPROF_PROFILE = {'f16x3': 'profiles/r05_rocprof_dominant_f16x3.json', 'bf16': 'profiles/r05_rocprof_dominant_bf16.json'}
 
 _T0 = time.perf_counter()
 
@@ -61,7 +63,8 @@ def parse(argv=None):
     ap.add_argument('--steps', type=int, default=None)
     ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--workload', default='adm64_eps_greedy', choices=['adm64_eps_greedy', 'ddpmpp32_rejection', 'adm64_mcts'])
-    ap.add_argument('--dtype', default='bf16', choices=DTYPE_NAMES, help='f32 = parity mode on the f32 MFMA; f16x3 = split precision on the 16-bit MFMA (near-f32 rewards)')
+    ap.add_argument('--dtype', default='f16x3', choices=DTYPE_NAMES, help='f16x3 (default) = split precision on the 16-bit MFMA: the mode that reproduces the reference\'s fp32 selections; '
+                    'f32 = parity mode on the f32 MFMA; bf16 / f16 = throughput modes (another sample after the first near-tied pick)')
     ap.add_argument('--candidates', type=int, default=None, help='candidates in total (strong, default 64) or per GPU (weak)')
     ap.add_argument('--scaling', default='strong', choices=['weak', 'strong'])
     ap.add_argument('--scorer', default='imagenet', choices=['imagenet', 'brightness'])
@@ -256,24 +259,44 @@ def conv_roofline(a, run_once, reps, dtype_name, value_per_gpu, gflop_per_eval, 
     kernels = {k_: dict(launches=v['launches'], tflops=round(v['gflop'] / max(v['ms'], 1e-9), 1), avg_launch_us=round(v['ms'] * 1e3 / v['launches'], 2),
                         alg_mb_per_launch=round(v['alg_mb'] / v['launches'], 1)) for k_, v in per_kernel.items()}
     dom_family = max(per_kernel, key=lambda k_: per_kernel[k_]['ms'])
-    traffic, tsrc = None, None
+    traffic, tsrc, rp = None, None, None
+    headline_shape = a.workload == 'adm64_eps_greedy' and a.candidates == 64 and a.gpus == 1
     try:        # HBM bytes per launch of the dominant kernel: a STATIC figure from committed rocprofv3 --pmc passes of this very
-        # command (counters cannot be collected from inside the process), valid for the default workload/dtype only
-        with open(os.path.join(ROOT, TRAFFIC_PROFILE)) as f:
-            doc = json.load(f)
-        if a.workload == 'adm64_eps_greedy' and dtype_name == 'bf16' and a.candidates == 64 and a.gpus == 1:
+        # command in this dtype (counters cannot be collected from inside the process), valid for the default workload only
+        if headline_shape and dtype_name in TRAFFIC_PROFILE:
+            with open(os.path.join(ROOT, TRAFFIC_PROFILE[dtype_name])) as f:
+                doc = json.load(f)
             traffic = round(doc['kernels_by_family'][dom_family]['hbm_bytes_per_launch'])
-            tsrc = (f'static, from {TRAFFIC_PROFILE} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of this command, collected at commit '
+            tsrc = (f'static, from {TRAFFIC_PROFILE[dtype_name]} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of this command, collected at commit '
                     f'{doc.get("collected_at_commit", "unknown")}; counters cannot be read from inside the process, so NOT measured in this run)')
     except Exception:
         pass
+    try:        # the same kernel's average duration in the rocprofv3 --kernel-trace --stats run of this command (static, like the counters):
+        # a profiled process runs several per cent slower (MI355X_MICROARCH.md, DVFS give-back item 2), so both figures are carried
+        if headline_shape and dtype_name in ROCPROF_PROFILE:
+            with open(os.path.join(ROOT, ROCPROF_PROFILE[dtype_name])) as f:
+                rp = json.load(f)
+    except Exception:
+        rp = None
     # the DOMINANT kernel = the conv kernel with the most time in the step (conv_pp_kernel on the ADM workload: the 3x3 layers); its
     # numbers are the top-level ones (what `rocprofv3 --kernel-trace --stats` reports for that kernel name must agree with avg_launch_us);
     # the aggregate over every implicit-GEMM conv launch of the step is kept beside it
     dom = max(per_kernel, key=lambda k_: per_kernel[k_]['ms'])
     d = per_kernel[dom]
     dach = d['gflop'] / d['ms']            # GFLOP / ms = TFLOP/s
-    return {'bound': 'mfma', 'achieved': round(dach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(dach / peak, 4),
+    x3 = dtype_name == 'f16x3'
+    out_extra = {}
+    if x3:      # split precision: three 16-bit matrix products per algorithmic multiply-add
+        out_extra['matrix_work_frac'] = round(3 * dach / peak, 4)
+        out_extra['how'] = ('achieved / frac count ALGORITHMIC FLOPs (one per multiply-add pair); matrix_work_frac counts the three f16 products each costs. '
+                            'The events bracket the conv kernel only: where a layer\'s input is not already a split image (skip / concat inputs) a dts_split3_f16 '
+                            'pass precedes it and is NOT in avg_launch_us; whole_step_frac includes everything')
+    if rp is not None and rp.get('kernel_family') == dom:
+        rus = float(rp['avg_launch_us'])
+        out_extra['rocprof_avg_launch_us'] = round(rus, 2)
+        out_extra['rocprof_frac'] = round(d['gflop'] / d['launches'] / (rus * 1e-3) / peak, 4)      # GFLOP / ms = TFLOP/s
+        out_extra['rocprof_source'] = f"static, {ROCPROF_PROFILE[dtype_name]} (rocprofv3 --kernel-trace --stats of this command at commit {rp.get('collected_at_commit', 'unknown')}, {rp.get('calls')} calls)"
+    return {'bound': 'mfma', 'achieved': round(dach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(dach / peak, 4), **out_extra,
             'traffic': traffic, 'traffic_source': tsrc, 'kernel': dom, 'launches': d['launches'],
             'avg_launch_us': round(d['ms'] * 1e3 / d['launches'], 2), 'avg_launch_gflop': round(d['gflop'] / d['launches'], 3),
             'alg_mb_per_launch': round(d['alg_mb'] / d['launches'], 1), 'ms_per_step': round(d['ms'] / reps, 2),
@@ -410,16 +433,20 @@ def scorer_dtype(dtype):
     return torch.float16 if dtype == torch.bfloat16 else dtype
 
 
-def build_adm(job, dtype, with_scorer=True, scorer_name='imagenet', sd=None, head_scale=None):
+def build_adm(job, dtype, with_scorer=True, scorer_name='imagenet', sd=None, head_scale=None, with_net=True):
+    """with_net=False: the scorer alone (net and state dict come back as None): the decidable-fixture legs need a second classifier head,
+    not a second 296 M-parameter denoiser."""
     import warnings
     from diffusion_tts_amd import init as dinit
     from diffusion_tts_amd.config import adm_imagenet64
     from diffusion_tts_amd.networks import EDMPrecond
     from diffusion_tts_amd.scorers import ImageNetScorer, BrightnessScorer
     cfg = adm_imagenet64()
-    if sd is None:
-        sd, _ = dinit.refill_degenerate(dinit.edm_state_dict(cfg, 0), 0)
-    net = EDMPrecond(cfg, sd, device=job.dev, dtype=dtype)
+    net = None
+    if with_net:
+        if sd is None:
+            sd, _ = dinit.refill_degenerate(dinit.edm_state_dict(cfg, 0), 0)
+        net = EDMPrecond(cfg, sd, device=job.dev, dtype=dtype)
     scorer = None
     if with_scorer:
         with warnings.catch_warnings():
@@ -603,6 +630,9 @@ def parity_mode_records(a, job, nets):
     the f32 parity mode (v_mfma_f32_16x16x4_f32, peak 157.3 TFLOP/s) and the split-precision mode f16x3 (16-bit MFMA, three passes)."""
     out = {}
     for name in ('f32', 'f16x3'):
+        if name == a.dtype:         # the headline IS this mode: its record is the line itself
+            out[name] = 'the headline of this line (value / ms_per_step / roofline above)'
+            continue
         net, scorer = nets[name]
         it = EpsGreedyIteration(job, net, scorer, 64)
         for s_ in range(3):
@@ -621,7 +651,7 @@ def parity_mode_records(a, job, nets):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-def sub_records(a, job, net, scorer, dtype, sd):
+def sub_records(a, job, net, scorer, dtype, sd, bf16_pair=None):
     """The other numbers DESIGN.md quotes, measured in the SAME driver-run process as the headline (each with its own ms_per_step and
     roofline): the per-GPU share of an 8-GPU run (8 candidates), BASELINE configs[1] at 32x32 with its own CPU baseline, an MCTS slice
     (configs[4] at S = --mcts-slice) and the iteration with the reference's fp32 scorer arithmetic (main.py:69)."""
@@ -642,31 +672,43 @@ def sub_records(a, job, net, scorer, dtype, sd):
     out['share_8_per_gpu'] = {'value': round(v8, 2), 'unit': 'candidate U-Net steps/sec per GPU', 'ms_per_step': round(dt8 / 40 * 1e3, 3), 'steps': 40,
                               'candidates_per_gpu': 8, 'projected_8gpu_value': round(8 * v8, 1),
                               'note': 'the per-GPU work of --gpus 8 at N=64 (strong scaling), without the reward all-gather', 'roofline': roof8}
+    out['share_8_per_gpu']['dtype'] = a.dtype
+    out['share_8_per_gpu']['projected_8gpu_speedup_vs_this_line'] = 'projected_8gpu_value / value of this line (same dtype)'
     del it8
     log(f"sub-record share_8_per_gpu: {out['share_8_per_gpu']['ms_per_step']} ms/step")
-    # (2) the iteration with an fp32 classifier (the reference scores in fp32, main.py:69): what exact-precision scoring costs
-    import warnings
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        sc32 = ImageNetScorer(device=job.dev, compute_dtype=torch.float32, seed=1)
-    it32 = EpsGreedyIteration(job, net, sc32, 64)
-    for s in range(3):
-        it32(s)
-    dt32 = job.timed(it32, 10, 2)
-    out['f32_scorer'] = {'value': round(2 * 64 * 10 / dt32, 2), 'unit': 'candidate U-Net steps/sec', 'ms_per_step': round(dt32 / 10 * 1e3, 3), 'steps': 10,
-                         'config': f'{a.dtype} denoiser + float32 classifier (parity-mode scorer kernels), N=64',
-                         'whole_step_frac': round(2 * 64 * 10 / dt32 * GFLOP_PER_EVAL['adm64'] * 1e9 / (PEAK_TFLOPS[a.dtype] * 1e12), 4)}
-    del it32, sc32
-    log(f"sub-record f32_scorer: {out['f32_scorer']['ms_per_step']} ms/step")
+    if bf16_pair is not None:       # the same 8-row share in the bf16 throughput mode (rounds 1-4 quoted this one)
+        itb = EpsGreedyIteration(job, bf16_pair[0], bf16_pair[1], 8)
+        for s in range(3):
+            itb(s)
+        dtb = job.timed(itb, 40, 3)
+        out['share_8_per_gpu_bf16'] = {'value': round(2 * 8 * 40 / dtb, 2), 'unit': 'candidate U-Net steps/sec per GPU', 'ms_per_step': round(dtb / 40 * 1e3, 3),
+                                       'steps': 40, 'candidates_per_gpu': 8, 'dtype': 'bf16', 'projected_8gpu_value': round(8 * 2 * 8 * 40 / dtb, 1)}
+        del itb
+        log(f"sub-record share_8_per_gpu_bf16: {out['share_8_per_gpu_bf16']['ms_per_step']} ms/step")
+    if a.dtype in ('bf16', 'f16'):
+        # (2) a 16-bit denoiser with an fp32 classifier (the reference scores in fp32, main.py:69): what exact-precision scoring costs beside it
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            sc32 = ImageNetScorer(device=job.dev, compute_dtype=torch.float32, seed=1)
+        it32 = EpsGreedyIteration(job, net, sc32, 64)
+        for s in range(3):
+            it32(s)
+        dt32 = job.timed(it32, 10, 2)
+        out['f32_scorer'] = {'value': round(2 * 64 * 10 / dt32, 2), 'unit': 'candidate U-Net steps/sec', 'ms_per_step': round(dt32 / 10 * 1e3, 3), 'steps': 10,
+                             'config': f'{a.dtype} denoiser + float32 classifier (parity-mode scorer kernels), N=64',
+                             'whole_step_frac': round(2 * 64 * 10 / dt32 * GFLOP_PER_EVAL['adm64'] * 1e9 / (PEAK_TFLOPS[a.dtype] * 1e12), 4)}
+        del it32, sc32
+        log(f"sub-record f32_scorer: {out['f32_scorer']['ms_per_step']} ms/step")
     # (3) MCTS slice (BASELINE configs[4] shape at a smaller S)
     rec = mcts_record(a, job, a.mcts_slice, 1, 0, built=(net, scorer))
-    out['mcts_s'] = {k_: rec[k_] for k_ in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'config', 'roofline')}
+    out['mcts_s'] = {k_: rec[k_] for k_ in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'dtype', 'config', 'roofline')}
     log(f"sub-record mcts_s (S={a.mcts_slice}): {rec['value']} evals/s")
     # (4) BASELINE configs[1]: DDPM++ CIFAR-32 rejection N=16 with its CPU baseline
     a32 = copy.copy(a)
     a32.conv_table, a32.conv_sequence, a32.workload, a32.candidates = False, None, 'ddpmpp32_rejection', 16
-    rec = rejection32_record(a32, job, steps=40, warmup=3)
-    out['ddpmpp32_rejection'] = {k_: rec[k_] for k_ in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'config', 'roofline', 'cpu_baseline')}
+    rec = rejection32_record(a32, job, steps=20 if a.dtype in ('f16x3', 'f32') else 40, warmup=3)
+    out['ddpmpp32_rejection'] = {k_: rec[k_] for k_ in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'dtype', 'config', 'roofline', 'cpu_baseline')}
     log(f"sub-record ddpmpp32_rejection: {rec['value']} evals/s, cpu {rec['cpu_baseline']}")
     # (5) BASELINE configs[3] with this build's parts: SD beam B=4 N=16 over [N,4,64,64] fp16 latents -> [N,3,512,512] decodes
     try:
@@ -786,29 +828,42 @@ def run_eps_greedy(a, job):
                 # the same on the second fixture: classifier output head x 20 (logit std ~3.4, init.scale_classifier_head)
                 from diffusion_tts_amd import init as dinit
                 hs = dinit.HEAD_SCALE_DECIDABLE
-                nets_h = {k: (nets[k][0], build_adm(job, torch_dtype(k), sd=sd, head_scale=hs)[1]) for k in modes}
+                nets_h = {k: (nets[k][0], build_adm(job, torch_dtype(k), head_scale=hs, with_net=False)[1]) for k in modes}
                 extra['parity']['index_agreement_scaled_head'] = dict(teacher_forced_agreement(job, nets_h, n=64), head_scale=hs,
                     fixture='same constructors and seeds, AttentionPool2d.c_proj x head_scale in oracle and build alike')
                 log(f"whole-search index agreement, scaled head: {extra['parity']['index_agreement_scaled_head']}")
                 del nets_h
                 extra['parity']['free_running_vs_f32'] = free_running_vs_f32(job, {k: nets[k] for k in modes})
                 log(f"free-running searches vs f32: {extra['parity']['free_running_vs_f32']}")
+                fr = extra['parity']['free_running_vs_f32'].get(a.dtype)
+                # north star: selected indices bit-exact, final images within 1e-3 abs -- for the mode `value` is measured in
+                extra['parity']['headline'] = ({'dtype': a.dtype, 'reference': 'GPU f32 parity mode (equal to the CPU oracle in tests/, which the reference\'s own goldens pin)',
+                                                'same_selections': fr['same_selections'], 'max_abs_x_final': fr['max_abs_x_final_vs_f32'],
+                                                'meets_north_star': bool(fr['same_selections'] == '72/72' and fr['max_abs_x_final_vs_f32'] <= 1e-3)}
+                                               if fr is not None else {'dtype': a.dtype, 'reference': 'this IS the f32 parity mode'})
                 extra['parity_modes'] = parity_mode_records(a, job, nets)
-            # the same timed region in the other 16-bit type (f16 is the reference's own CUDA dtype, networks.py:658): both throughput
-            # figures and both index-agreement figures then sit in ONE driver-run record
-            other = 'f16' if a.dtype == 'bf16' else ('bf16' if a.dtype == 'f16' else None)
-            if other is not None:
+            # the same timed region in the 16-bit THROUGHPUT modes (f16 is the reference's own CUDA dtype, networks.py:658): every throughput and
+            # index-agreement figure then sits in ONE driver-run record.  They do not reproduce the reference's selections (parity.free_running_vs_f32).
+            others = [m for m in ('bf16', 'f16') if m != a.dtype]
+            extra['other_dtype'] = {}
+            for other in others:
                 ito = EpsGreedyIteration(job, nets[other][0], nets[other][1], n_total)
                 for s in range(3):
                     ito(s)
-                dto = job.timed(ito, a.steps, a.warmup)
-                extra['other_dtype'] = {'dtype': other, 'value': round(2 * n_total * a.steps / dto, 2), 'ms_per_step': round(dto / a.steps * 1e3, 3),
-                                        'whole_step_frac': round(2 * n_total * a.steps / dto * GFLOP_PER_EVAL['adm64'] * 1e9 / (PEAK_TFLOPS[other] * 1e12), 4)}
+                st_o = max(a.steps, 10)
+                dto = job.timed(ito, st_o, a.warmup)
+                extra['other_dtype'][other] = {'value': round(2 * n_total * st_o / dto, 2), 'ms_per_step': round(dto / st_o * 1e3, 3), 'steps': st_o,
+                                               'scorer_dtype': str(scorer_dtype(torch_dtype(other))).split('.')[-1],
+                                               'whole_step_frac': round(2 * n_total * st_o / dto * GFLOP_PER_EVAL['adm64'] * 1e9 / (PEAK_TFLOPS[other] * 1e12), 4),
+                                               'note': 'throughput mode: NOT the reference\'s selections on the same seed (see parity.free_running_vs_f32)'}
                 del ito
-                log(f"{other}: {extra['other_dtype']['value']} evals/s")
+                log(f"{other}: {extra['other_dtype'][other]['value']} evals/s")
+            nets_tp = nets.get('bf16')
             del nets
+        else:
+            nets_tp = None
         if not a.no_subrecords and a.candidates == 64 and a.scorer == 'imagenet':
-            extra['sub_records'] = sub_records(a, job, net, scorer, dtype, sd)
+            extra['sub_records'] = sub_records(a, job, net, scorer, dtype, sd, bf16_pair=nets_tp if a.dtype != 'bf16' else None)
     if rank == 0:
         out = {
             'metric': 'candidate U-Net steps/sec, EDM ImageNet-64 eps-greedy N=64', 'value': round(value, 2),
@@ -821,7 +876,9 @@ def run_eps_greedy(a, job):
                        'denoiser_dtype': a.dtype,
                        # every forward of the timed region was a replayed HIP graph (a refused capture is an ERROR under bench.py: DTS_GRAPHS_STRICT)
                        'graph_replay': bool(net._graphs.enabled and graph_replays > 0), 'graph_replays_in_timed_region': graph_replays,
-                       'reuse_winner': 'n/a: a bench step evaluates all N candidates; generate_image_grid (e2e_evals_per_s) reuses the winner row in the 16-bit modes',
+                       'reuse_winner': 'n/a: a bench step evaluates all N candidates.  generate_image_grid (e2e_rows): f16x3 / f32 recompute the final pivot step at batch 1 like '
+                                       'edm/main.py:860 (8 995 rows per config-3 search = the reference\'s count); bf16 / f16 reuse the winner\'s row (8 960 rows, same values)',
+                       'parity_grade': a.dtype in ('f16x3', 'f32'),
                        'parallelism': f'candidates sharded x{world}, 1 all-gather of rewards per step'},
             'rccl_ranks': world if (world > 1 and job.backend == 'nccl') else (0 if world > 1 else 1),
             'dist_backend': job.backend, 'weak_value': None if weak is None else round(weak, 2),

@@ -63,13 +63,14 @@ SIGNATURES = {
     'dts_take_token': [_p, _i, _p, _i, _i, _i, _i, _p],
     'dts_softmax_gather': [_p, _p, _p, _i, _i, _p],
     'dts_candidate_noise': [_p, _p, _p, _p, _p, _i, _i, _i, _p],
+    'dts_candidate_noise_sd': [_p, _p, _p, _p, _p, _i, _i, _i64, _p],
     'dts_cfg_combine': [_p, _p, _f, _p, _i, _i64, _p],
     'dts_ddim_candidates': [_p, _p, _p, _p, _p, _i, _f, _f, _f, _i, _i64, _p],
 }
 OTHER = {'dts_version': ([], _i), 'dts_conv_fuses_gn': ([C.POINTER(ConvArgs)], _i), 'dts_conv_kernel': ([C.POINTER(ConvArgs)], _i), 'dts_set_tuning': ([_i, _i], _i), 'dts_get_tuning': ([_i], _i), 'dts_last_error': ([], C.c_char_p), 'dts_gn_ws_floats': ([_i, _i], _i64)}
 
 _lib = None
-ABI_VERSION = 108              # include/dts.h DTS_ABI_VERSION this binding was written against (ConvArgs = 184 bytes)
+ABI_VERSION = 109              # include/dts.h DTS_ABI_VERSION this binding was written against (ConvArgs = 184 bytes)
 
 
 def load():

@@ -76,7 +76,7 @@ def check_m0(obj):
     that names m0 must be one of our own `s_mov_b32 m0, s<N>` (or vcc_lo / vcc_hi as the scalar source) (the LDS-DMA loads read M0
     implicitly).  It also pins the second assumption of those kernels: the LDS-DMA loads are awaited with hand-counted `s_waitcnt vmcnt(N)`,
     and a register spill to scratch would put compiler-generated vmcnt-counted memory operations inside the counted window -- so every
-    kernel of the object that issues LDS-DMA (names m0) with a counted wait (all but the 2-deep-ring conv_igemm_kernel) must have no scratch (.private_segment_fixed_size == 0) and no VGPR spill.
+    kernel of the object that issues LDS-DMA (names m0) must have no scratch (.private_segment_fixed_size == 0) and no VGPR spill.
     Returns the number of M0 writes; raises if anything else touches M0 or such a kernel spills."""
     import tempfile
     if not os.path.exists(OBJDUMP):
@@ -105,14 +105,13 @@ def check_m0(obj):
     if bad or not uses:
         raise RuntimeError(f'{name} code object: {len(bad)} instruction(s) other than our `s_mov_b32 m0, sN` use M0 '
                            f'(first: {bad[:3]}); the M0-clobber shortcut of the LDS-DMA helpers is no longer safe')
-    # conv_igemm_kernel<..., STAGES = 2> awaits its LDS-DMA with vmcnt(0) only (nothing counted), so a spill there costs time, not
-    # correctness (the f32 192-cout tile, reachable only through DTS_CONV_TILE=192, spills 36 bytes); every other LDS-DMA kernel counts
-    uncounted = re.compile(r'^_ZN\d+_GLOBAL__N_117conv_igemm_kernelI.*Li2EEEvNS_5ConvPE$')
+    # (no exemption: since round 4 every LDS-DMA kernel of the library -- the 2-deep-ring conv_igemm_kernel forms with their uncounted
+    # vmcnt(0) waits included -- compiles without scratch, and a spill in any of them should fail the build rather than cost time silently)
     if notes:
         spilled = []
         for blk in re.split(r'\n\s+- \.agpr_count', notes)[1:]:
             g = lambda k: re.search(r'\.%s:\s+(\S+)' % k, blk).group(1)
-            if g('name') in dma_kernels and not uncounted.match(g('name')) and (int(g('private_segment_fixed_size')) != 0 or int(g('vgpr_spill_count')) != 0):
+            if g('name') in dma_kernels and (int(g('private_segment_fixed_size')) != 0 or int(g('vgpr_spill_count')) != 0):
                 spilled.append((g('name'), int(g('private_segment_fixed_size')), int(g('vgpr_spill_count'))))
         if spilled:
             raise RuntimeError(f'{name}: LDS-DMA kernels with scratch / VGPR spills (their hand-counted vmcnt waits would no longer hold): {spilled[:3]}')

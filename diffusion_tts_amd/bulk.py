@@ -14,6 +14,7 @@ from typing import Any, Dict, Iterable, List, Optional
 import torch
 import torch.distributed as dist
 
+from . import ops
 from .sampler import SamplingMethod, generate_image_grid, load_network
 
 
@@ -52,7 +53,7 @@ def seed_inputs(seed: int, net, class_idx: Optional[int] = None):
 @torch.no_grad()
 def generate_seeds(network, seeds, outdir, *, sampling_method=SamplingMethod.NAIVE, sampling_params: Optional[Dict[str, Any]] = None,
                    class_idx: Optional[int] = None, max_batch_size: int = 64, subdirs: bool = False, device='cuda',
-                   compute_dtype=torch.bfloat16, verbose=False, **sampler_kwargs):
+                   compute_dtype=ops.F16X3, verbose=False, **sampler_kwargs):
     """Returns {seed: result dict of generate_image_grid} for the seeds this rank generated."""
     dist_on = dist.is_available() and dist.is_initialized()
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist_on else (0, 1)

@@ -30,7 +30,7 @@ class _P:
 
 
 class EncoderUNetModel:
-    def __init__(self, cfg: ClassifierConfig, state_dict: Dict[str, torch.Tensor], device='cuda', dtype=torch.bfloat16):
+    def __init__(self, cfg: ClassifierConfig, state_dict: Dict[str, torch.Tensor], device='cuda', dtype=ops.F16X3):
         if not torch.cuda.is_available():
             raise RuntimeError('EncoderUNetModel (HIP) needs a GPU: there is no CPU fallback in this package')
         self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
@@ -102,7 +102,7 @@ class EncoderUNetModel:
         fx3 = self.x3 and ops.attention_x3_ok(hh * ww, c // P.heads)        # (see networks.EDMPrecond._block)
         qkv = ops.conv2d(hn, P.wqkv, P.bqkv, out_split2=fx3)
         a = ops.attention(qkv.view(n, hh * ww, 3 * c), P.heads, 1.0 / math.sqrt(c // P.heads), x3=self.x3, split_out=fx3)
-        a = ops.SplitAct(a.data.view(n, hh, ww, 3 * c), c) if fx3 else a.view(n, hh, ww, c)
+        a = ops.SplitAct(a.data.view(n, hh, ww, 2 * c), c) if fx3 else a.view(n, hh, ww, c)
         return ops.conv2d(a, P.wproj, P.bproj, residual=x, gn_stats=True)
 
     @torch.no_grad()

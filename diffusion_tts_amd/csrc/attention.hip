@@ -58,7 +58,7 @@ struct AttP {
   float scale_log2e;
   int qblocks;                   // query blocks per (sample, head)
   int xcd_remap;                 // 1: XCD-aware block order (default); 0: plain order (A/B aid, DTS_ATT_XCD=0)
-  int out_split3;                // attention_x3_kernel: the output leaves as the split-precision conv operand image hi | lo * 2^11 | hi (f16 [n][t][3C])
+  int out_split3;                // attention_x3_kernel: the output leaves as the split-precision conv operand image, per 32 channels hi | lo * 2^11 (f16 [n][t][2C])
 };
 
 // Block order.  The grid is 1-D over (sample*head, query block), (sample, head)-major.  Hardware deals consecutive block ids
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const AttP p) {
       if (p.out_split3) {
         // the only reader is the proj convolution of the split-precision mode: write its operand image (dts_split3_f16's arithmetic)
         // instead of the f32 tensor + a split pass
-        f16_t* orow3 = reinterpret_cast<f16_t*>(p.out) + ((size_t)n * p.t + qrow) * 3 * C + head * D;
+        f16_t* orow3 = reinterpret_cast<f16_t*>(p.out) + ((size_t)n * p.t + qrow) * 2 * C;      // rows of 2C f16: per 32 channels hi(32) | lo(32)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
           float hi[4], lo[4];
@@ -591,16 +591,11 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const AttP p) {
           for (int r = 0; r < 4; ++r) {
             float x = o[qt][dt][r] * inv;
             asm volatile("" : "+v"(x));                    // the ROUNDED product (no FMA contraction into the subtraction below): the value the f32 output holds
-            float h = f16_bits_to_f32(f32_to_f16_bits(x));
-            if (fabsf(h) < 6.103515625e-05f) h = 0.f;
-            hi[r] = h;
-            lo[r] = (x - h) * 2048.0f;
+            x3_split(x, hi[r], lo[r]);
           }
-          const uint2 h2 = make_uint2(pack2_f16(hi[0], hi[1]), pack2_f16(hi[2], hi[3])), l2 = make_uint2(pack2_f16(lo[0], lo[1]), pack2_f16(lo[2], lo[3]));
-          f16_t* d_ = orow3 + dt * 16 + lg * 4;
-          *reinterpret_cast<uint2*>(d_) = h2;
-          *reinterpret_cast<uint2*>(d_ + C) = l2;
-          *reinterpret_cast<uint2*>(d_ + 2 * C) = h2;
+          f16_t* d_ = orow3 + x3_off(head * D + dt * 16 + lg * 4);
+          *reinterpret_cast<uint2*>(d_) = make_uint2(pack2_f16(hi[0], hi[1]), pack2_f16(hi[2], hi[3]));
+          *reinterpret_cast<uint2*>(d_ + 32) = make_uint2(pack2_f16(lo[0], lo[1]), pack2_f16(lo[2], lo[3]));
         }
       } else {
         float* orow = reinterpret_cast<float*>(p.out) + ((size_t)n * p.t + qrow) * C + head * D;

@@ -84,6 +84,13 @@ template <> struct Mma<float> {
   }
 };
 
+// the 8 f16 values of a fragment register quad times 2^-11 (4 x v_pk_mul_f16; exact while the result stays a normal number): the
+// split-precision mode's weight operand for the activations' lo * 2^11 half (see conv_igemm_kernel's X3I note)
+__device__ __forceinline__ uint4 f16x8_mul_2m11(const uint4& v) {
+  const f16x8_t h = __builtin_bit_cast(f16x8_t, v) * (_Float16)0x1p-11f;
+  return __builtin_bit_cast(uint4, h);
+}
+
 template <typename T> struct Vec4;
 template <> struct Vec4<float> {
   using type = float4;
@@ -511,11 +518,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
         // separate split pass (4 B written + 4 B read per element) are skipped
         float hi[4], lo[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float y = v[r] * 64.0f;
-          hi[r] = f16_bits_to_f32(f32_to_f16_bits(y));
-          lo[r] = y - hi[r];
-        }
+        for (int r = 0; r < 4; ++r) x2_split(v[r], hi[r], lo[r]);
         f16_t* orow = reinterpret_cast<f16_t*>(kp.out) + (size_t)ppv[nt] * 2 * p_cout + co;
         *reinterpret_cast<uint2*>(orow) = make_uint2(pack2_f16(hi[0], hi[1]), pack2_f16(hi[2], hi[3]));
         *reinterpret_cast<uint2*>(orow + p_cout) = make_uint2(pack2_f16(lo[0], lo[1]), pack2_f16(lo[2], lo[3]));
@@ -566,7 +569,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
 // block per CU (the small per-GPU batches of a sharded search, MCTS groups, the 8x8 level), where a 2-deep ring makes every K step one
 // full L2 round trip (~2.1k cycles against 768 cycles of MFMAs).
 // OT: element type of the epilogue's operands and of the output (bias_nc, residual, out).  OT = T everywhere except the split-precision
-// mode (T = f16 operand planes [hi | lo | hi] against weights [hi | hi | lo], OT = float: dts.h DTS_F16X3), whose epilogue is the f32 one.
+// mode (T = f16, OT = float: dts.h DTS_F16X3), whose epilogue is the f32 one and whose K loop is the X3I form:
+// X3I (round 5).  An f32 activation x = hi + lo and an f32 weight w = wh + wl (f16 parts) give x.w ~ hi.wh + lo.wh + hi.wl.  The operand
+// images interleave the parts per 32 channels: a 128-byte K-step row of the activations is [hi(32) | lo * 2^11 (32)], of the weights
+// [wh(32) | wl(32)], so ONE staged K step (the same LDS-DMA pieces and fragment reads as a 16-bit step) feeds THREE MFMAs per accumulator
+// tile: (wh, hi), (wh * 2^-11, lo * 2^11), (wl, hi) -- the scaled copy of the wh fragment is made in registers (4 v_pk_mul_f16).  Round 4
+// staged three separate K steps (planes hi | lo | hi against hi | hi * 2^-11 | lo): 1.5 x the LDS-DMA pieces, fragment reads and HBM bytes
+// per product for the same MFMAs.
 template <typename T, int MT, int NT, int WM, int WN, bool PF, int STAGES = 2, typename OT = T>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || STAGES == 2 ? 2 : 1)) void conv_igemm_kernel(const ConvP kp) {
   const char* const p_x1 = kp.x1; const char* const p_x2 = kp.x2; const char* const p_w = kp.w;
@@ -578,6 +587,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || STAGES == 2 ? 2 : 1)
   // each) and THEN its 48 MFMAs -- 1900 cycles per K step, the matrix pipe idle 60 % of it (tools/conv_stamps.py); with two waves per
   // SIMD each issues 5 pieces and 24 MFMAs and one wave's issue stalls sit under the other's MFMAs.
   constexpr int NW = WM * WN;
+  constexpr bool X3I = !std::is_same<T, OT>::value;
+  static_assert(!X3I || std::is_same<T, f16_t>::value, "split precision runs on the f16 matrix instruction");
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
   constexpr int SLAB = 8 * NW;             // rows staged by one wave-instruction round of the whole block
@@ -765,11 +776,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || STAGES == 2 ? 2 : 1)
       if (early_u1 < early_u0) early_u1 = early_u0;
       issue_residual_pieces<BM, 64 * NW>(kp, cm0, linear_tile(pn0), lds_base + stage_off, tid, early_u0, early_u1);
     }
+    uint4 fs[X3I ? MT : 1];
+    if constexpr (X3I) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) fs[i] = f16x8_mul_2m11(fa[i]);                     // wh * 2^-11 (meets lo * 2^11)
+    }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
+      for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);              // (X3I: wh . hi)
     if (!PF) {
       __builtin_amdgcn_s_setprio(0);
 #pragma unroll
@@ -778,10 +794,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 || STAGES == 2 ? 2 : 1)
       for (int i = 0; i < MT; ++i) ga[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq + 4));
       __builtin_amdgcn_s_setprio(1);
     }
+    if constexpr (X3I) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], ga[i], gb[j]);
+        for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], fs[i], gb[j]);            // wh * 2^-11 . lo * 2^11
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], ga[i], fb[j]);            // wl . hi
+    } else {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], ga[i], gb[j]);
+    }
     __builtin_amdgcn_s_setprio(0);
     // next tile has landed (LDS-DMA completion is tracked by vmcnt, in issue order: the tiles issued after it may still fly) and
     // this wave's LDS reads of the current tile have returned
@@ -868,6 +895,10 @@ template <typename T, int TAPS, int DBG = 0, bool GN = false, int MT = 6, typena
 __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
   // MT = M tiles (of 16 couts) per wave: 6 -> 192-cout blocks (the EDM U-Net widths), 4 -> 128-cout blocks (classifier, SD VAE widths)
   static_assert(MT == 6 || MT == 4, "cout tile");
+  // X3I: the split-precision K loop (see conv_igemm_kernel): a K tile's rows are [hi | lo * 2^11] / [wh | wl] of 32 channels, and COMPUTE
+  // issues 3 x MT x NT MFMAs per tile instead of 2 x MT x NT -- a 1.5 x longer matrix segment per barrier pair for the same LOAD work
+  constexpr bool X3I = !std::is_same<T, OT>::value;
+  static_assert(!X3I || (std::is_same<T, f16_t>::value && DBG == 0 && !GN), "split precision: the shipped f16 form only");
   constexpr int NT = 4, GM = 16 * MT, BM = 2 * GM, BN = 256, NTHR = 512, AJ = MT / 2;      // AJ: A pieces (8 rows x 4 waves) per wave and tile
   constexpr int BKE = 64, ES = 2;
   constexpr int A_HALF = GM * 128, A_RING = 3 * A_HALF, H_OFF = 2 * A_RING, H_BUF = 328 * 128;       // see the LDS map above
@@ -1140,6 +1171,11 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
       }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // every fragment is in registers: slots / buffers may be refilled
+      uint4 fs[X3I ? MT : 1];
+      if constexpr (X3I) {                                 // wh * 2^-11, made HERE in LOAD (vector issue slots in COMPUTE are lost matrix cycles)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fs[i] = f16x8_mul_2m11(fa[i]);
+      }
       DTS_SEG_MARK(1)                                      // section 1: fragment reads issued and returned
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_barrier" ::: "memory");
@@ -1183,10 +1219,16 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
             // (forcing one MFMA : two VALU with sched_group_barrier made hipcc spill 342 VGPRs -- 835 evals/s; left to its scheduler)
           }
         }
+        if constexpr (X3I) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], fs[i], gb[j]);       // wh * 2^-11 . lo * 2^11
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
-          for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], ga[i], gb[j]);
+          for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], ga[i], X3I ? fb[j] : gb[j]);      // (X3I: wl . hi)
           if constexpr (A_IN_LOAD + 1 < AJ) {
             if (i == MT / 2 - 1) {
               __builtin_amdgcn_sched_barrier(0);

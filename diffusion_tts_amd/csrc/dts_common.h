@@ -96,6 +96,31 @@ __device__ __forceinline__ uint32_t f32_to_f16_bits(float f) {
   return (uint32_t)__builtin_bit_cast(uint16_t, h);
 }
 
+// ---- split-precision operand images (dts.h DTS_F16X3) -----------------------------------------------------------------------------
+// x -> (hi, lo * 2^11), both exactly representable in f16: hi = f16(x) (round to nearest even), lo = x - hi (exact in f32: the residual
+// of a rounding fits 13 bits).  The matrix cores flush f16 SUBNORMAL inputs (measured: tests/test_gpu_ops.py::test_conv2d_split_precision
+// [tiny_values]), so (1) a hi below 2^-14 is dropped and the whole value goes into the lo half, and (2) the lo half carries lo * 2^11 --
+// the kernels multiply the weight fragment that meets it by 2^-11 -- which keeps it a normal f16 number down to |x - hi| = 2^-25.
+// |x| beyond the f16 range SATURATES to +-65504 (a plain cast would give inf, and lo = x - inf a NaN that poisons every output the
+// element touches: ADVICE r4); a NaN stays a NaN.
+__device__ __forceinline__ void x3_split(float x, float& hi, float& lo) {
+  if (fabsf(x) > 65504.0f) x = copysignf(65504.0f, x);
+  float h = (float)(_Float16)x;
+  if (fabsf(h) < 6.103515625e-05f) h = 0.f;
+  hi = h;
+  lo = (x - h) * 2048.0f;
+}
+// Layout of the image: per pixel row, per group of 32 channels, 128 bytes = hi(32) | lo * 2^11 (32) -- one K step of a split-precision
+// convolution.  Element offset (in f16) of channel c's hi half inside a row of C channels; its lo half sits 32 elements further.
+__device__ __forceinline__ int x3_off(int c) { return ((c >> 5) << 6) + (c & 31); }
+// the attention operand split (dts_split2_f16's arithmetic): y = x * 2^6 -> (hi, lo), saturating like x3_split
+__device__ __forceinline__ void x2_split(float x, float& hi, float& lo) {
+  float y = x * 64.0f;
+  if (fabsf(y) > 65504.0f) y = copysignf(65504.0f, y);
+  hi = (float)(_Float16)y;
+  lo = y - hi;
+}
+
 template <typename T> __device__ __forceinline__ float ld1(const T* p);
 template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float ld1<bf16_t>(const bf16_t* p) { return bf16_bits_to_f32(p->v); }

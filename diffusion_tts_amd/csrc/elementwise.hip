@@ -435,6 +435,38 @@ __global__ __launch_bounds__(256) void candidate_noise_kernel(const double* __re
   for (int i = threadIdx.x; i < chw; i += blockDim.x) out[i] = pv[i] + sc * (gr[i] / nrm);
 }
 
+// K14 of the SD backend (pipeline_stable_diffusion.py:1371-1379): the same construction in the LATENTS' storage type T, rounding where
+// the reference's tensor ops round -- norm (f32 accumulation, result in T), u / norm (in T), * python scalar (f32 math, result in T),
+// pivot + ... (in T).  One block per candidate.
+template <typename T>
+__global__ __launch_bounds__(256) void candidate_noise_sd_kernel(const T* __restrict__ pivot, const T* __restrict__ u,
+                                                                  const int32_t* __restrict__ mode, const float* __restrict__ scale,
+                                                                  T* __restrict__ cand, int count) {
+  __shared__ float red[4];
+  const int cn = blockIdx.x;
+  const T* ur = u + (size_t)cn * count;
+  T* out = cand + (size_t)cn * count;
+  if (mode[cn] == 0) {                                        // fresh Gaussian (:1375)
+    for (int i = threadIdx.x; i < count; i += blockDim.x) out[i] = ur[i];
+    return;
+  }
+  float ss = 0.f;
+  for (int i = threadIdx.x; i < count; i += blockDim.x) { const float v = ld1<T>(ur + i); ss += v * v; }
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  T nrm_t;
+  st1<T>(&nrm_t, sqrtf((red[0] + red[1]) + (red[2] + red[3])));
+  const float nrm = ld1<T>(&nrm_t), sc = scale[cn];
+  for (int i = threadIdx.x; i < count; i += blockDim.x) {
+    T a, b, c;
+    st1<T>(&a, ld1<T>(ur + i) / nrm);                         // to_add / torch.norm(to_add)
+    st1<T>(&b, ld1<T>(&a) * sc);                              // * (rand * lambda * sqrt(numel)): python scalar, f32 math
+    st1<T>(&c, ld1<T>(pivot + i) + ld1<T>(&b));               // pivot + ...
+    out[i] = c;
+  }
+}
+
 // ---- K13 -----------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void ddim_candidates_kernel(const T* __restrict__ x, const T* __restrict__ e, const T* __restrict__ z, T* __restrict__ prev,
@@ -510,8 +542,8 @@ extern "C" int dts_pack_conv_weight(const float* w, void* dst, int dtype, int O,
   });
   return DTS_OK;
 }
-// split-precision operand image (dts.h DTS_F16X3): row p of concat(x1, x2) -> hi | lo * 2^11 | hi, 8 channels (two float4 in, three 16-byte
-// stores out) per thread.  HBM-bound: 4 bytes read + 6 written per element.
+// split-precision operand image (dts.h DTS_F16X3): row p of concat(x1, x2) -> per 32 channels hi(32) | lo * 2^11 (32); 8 channels (two float4
+// in, two 16-byte stores out) per thread.  HBM-bound: 4 bytes read + 4 written per element.
 __global__ __launch_bounds__(256) void split3_f16_kernel(const float* __restrict__ x1, int c1, const float* __restrict__ x2, int c2,
                                                           uint4* __restrict__ out, long long rows) {
   const int C = c1 + c2, nch = C / 8;
@@ -524,25 +556,15 @@ __global__ __launch_bounds__(256) void split3_f16_kernel(const float* __restrict
     const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     float hi[8], lo[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      // hi = f16(x), round to nearest even (|x| >= 65520 becomes inf, as a plain f16 cast would).  The matrix cores flush f16 SUBNORMAL
-      // inputs (measured: tests/test_gpu_ops.py::test_conv2d_split_precision[tiny_values]), so (1) a hi below 2^-14 is dropped and the
-      // whole value goes into the lo plane, and (2) the lo plane carries lo * 2^11 -- the packed weights of that K segment carry 2^-11 --
-      // which keeps it a normal f16 number down to |x - hi| = 2^-25.  x - hi is exact in f32 (the residual of a rounding fits 13 bits).
-      float h = f16_bits_to_f32(f32_to_f16_bits(f[e]));
-      if (fabsf(h) < 6.103515625e-05f) h = 0.f;
-      hi[e] = h;
-      lo[e] = (f[e] - h) * 2048.0f;
-    }
-    const uint4 h = pack16<f16_t>(hi), l = pack16<f16_t>(lo);
-    uint4* o = out + row * (3 * nch) + ch;
-    o[0] = h; o[nch] = l; o[2 * nch] = h;
+    for (int e = 0; e < 8; ++e) x3_split(f[e], hi[e], lo[e]);
+    uint4* o = out + row * (2 * nch) + ((ch >> 2) << 3) + (ch & 3);          // 16-byte slots: group (ch / 4) holds 4 hi slots, then 4 lo slots
+    o[0] = pack16<f16_t>(hi); o[4] = pack16<f16_t>(lo);
   }
 }
 
 // split-precision attention input (dts_attention_x3): row p of x (C channels) -> hi(C) | lo(C) of x * 2^6, hi = f16(y), lo = f16(y - hi).
 // The factor keeps the lo part a normal f16 number for |x| >= 2^-8 (the matrix cores flush subnormal inputs; below that the lo part,
-// <= 2^-20 |x|, is lost) and |x| must stay below 1023; the attention kernel takes the powers of two out again exactly.
+// <= 2^-20 |x|, is lost); |x| >= 1023.5 saturates (x2_split); the attention kernel takes the powers of two out again exactly.
 __global__ __launch_bounds__(256) void split2_f16_kernel(const float* __restrict__ x, int C, uint4* __restrict__ out, long long rows) {
   const int nch = C / 8;
   const long long total = rows * nch;
@@ -554,11 +576,7 @@ __global__ __launch_bounds__(256) void split2_f16_kernel(const float* __restrict
     const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     float hi[8], lo[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float y = f[e] * 64.0f;
-      hi[e] = f16_bits_to_f32(f32_to_f16_bits(y));
-      lo[e] = y - hi[e];
-    }
+    for (int e = 0; e < 8; ++e) x2_split(f[e], hi[e], lo[e]);
     uint4* o = out + row * (2 * nch) + ch;
     o[0] = pack16<f16_t>(hi); o[nch] = pack16<f16_t>(lo);
   }
@@ -574,7 +592,8 @@ extern "C" int dts_split2_f16(const float* x, int c, void* out, int64_t rows, dt
 }
 
 extern "C" int dts_split3_f16(const float* x1, int c1, const float* x2, int c2, void* out, int64_t rows, dts_stream s) {
-  DTS_CHECK_ARG(x1 && out && rows >= 0 && c1 > 0 && c1 % 8 == 0 && c2 >= 0 && c2 % 8 == 0, "dts_split3_f16: bad args (c1=%d c2=%d)", c1, c2);
+  DTS_CHECK_ARG(x1 && out && rows >= 0 && c1 > 0 && c1 % 8 == 0 && c2 >= 0 && c2 % 8 == 0 && (c1 + c2) % 32 == 0,
+                "dts_split3_f16: bad args (c1=%d c2=%d: multiples of 8, sum a multiple of 32)", c1, c2);
   DTS_CHECK_ARG(c2 == 0 || x2, "dts_split3_f16: c2 without x2");
   if (rows == 0) return DTS_OK;
   ST;
@@ -762,6 +781,18 @@ extern "C" int dts_candidate_noise(const double* pivot, const double* g, const i
   ST;
   hipLaunchKernelGGL(candidate_noise_kernel, dim3(nb), dim3(256), 0, st, pivot, g, mode, scale, cand, b, chw);
   DTS_CHECK_LAUNCH("dts_candidate_noise");
+  return DTS_OK;
+}
+
+extern "C" int dts_candidate_noise_sd(const void* pivot, const void* u, const int32_t* mode, const float* scale, void* cand, int dtype, int n,
+                                      int64_t count, dts_stream s) {
+  DTS_CHECK_ARG(pivot && u && mode && scale && cand, "dts_candidate_noise_sd: null pointer");
+  DTS_CHECK_ARG(n > 0 && count > 0 && count < (1ll << 31), "dts_candidate_noise_sd: n=%d count=%lld", n, (long long)count);
+  ST;
+  DTS_DISPATCH_DTYPE(dtype, {
+    hipLaunchKernelGGL((candidate_noise_sd_kernel<T>), dim3(n), dim3(256), 0, st, (const T*)pivot, (const T*)u, mode, scale, (T*)cand, (int)count);
+    DTS_CHECK_LAUNCH("dts_candidate_noise_sd");
+  });
   return DTS_OK;
 }
 

@@ -171,22 +171,16 @@ __global__ __launch_bounds__(256) void gn_coef_strips_kernel(const float* __rest
 template <typename T> __device__ __forceinline__ float silu_t(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 template <> __device__ __forceinline__ float silu_t<float>(float x) { return silu_f(x); }
 
-// Split-precision output (dts.h DTS_F16X3, the arithmetic of split3_f16_kernel): 4 consecutive channels c0.. of one pixel row of C
-// channels go out as f16 hi | lo * 2^11 | hi at channel offsets c0, C + c0, 2C + c0 of the 3C-wide row `orow` -- what the consuming
+// Split-precision output (dts.h DTS_F16X3, the arithmetic of split3_f16_kernel): 4 consecutive channels c0.. of one pixel row go out as
+// f16 hi / lo * 2^11 into the 2C-wide row `orow` of the operand image (per 32 channels: hi(32) | lo(32)) -- what the consuming
 // convolution reads, so the f32 tensor in between (one write + one read) and the separate split pass disappear.
-__device__ __forceinline__ void store_split4(f16_t* orow, int C, int c0, const float* f) {
+__device__ __forceinline__ void store_split4(f16_t* orow, int c0, const float* f) {
   float hi[4], lo[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float h = f16_bits_to_f32(f32_to_f16_bits(f[e]));
-    if (fabsf(h) < 6.103515625e-05f) h = 0.f;            // the matrix cores flush f16 subnormals: the whole value goes to the lo plane
-    hi[e] = h;
-    lo[e] = (f[e] - h) * 2048.0f;
-  }
-  const uint2 h2 = make_uint2(pack2_f16(hi[0], hi[1]), pack2_f16(hi[2], hi[3])), l2 = make_uint2(pack2_f16(lo[0], lo[1]), pack2_f16(lo[2], lo[3]));
-  *reinterpret_cast<uint2*>(orow + c0) = h2;
-  *reinterpret_cast<uint2*>(orow + C + c0) = l2;
-  *reinterpret_cast<uint2*>(orow + 2 * C + c0) = h2;
+  for (int e = 0; e < 4; ++e) x3_split(f[e], hi[e], lo[e]);
+  f16_t* d = orow + x3_off(c0);
+  *reinterpret_cast<uint2*>(d) = make_uint2(pack2_f16(hi[0], hi[1]), pack2_f16(hi[2], hi[3]));
+  *reinterpret_cast<uint2*>(d + 32) = make_uint2(pack2_f16(lo[0], lo[1]), pack2_f16(lo[2], lo[3]));
 }
 
 // Apply pass, row form: a block works on a pixel range of ONE sample and every thread keeps ONE 16-byte channel chunk, so
@@ -211,7 +205,7 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const T* __restrict_
   const T* src; int cs;
   if (c0 < c1) { src = x1 + (size_t)n * hw * c1 + c0; cs = c1; } else { src = x2 + (size_t)n * hw * c2 + (c0 - c1); cs = c2; }
   T* dst = out + (size_t)n * hw * C + c0;
-  f16_t* const dst3 = reinterpret_cast<f16_t*>(out) + (size_t)n * hw * 3 * C;       // SPLIT: rows of 3C f16
+  f16_t* const dst3 = reinterpret_cast<f16_t*>(out) + (size_t)n * hw * 2 * C;       // SPLIT: rows of 2C f16
   const int p_begin = blockIdx.x * ppb, p_end = min(hw, p_begin + ppb);
   int p = p_begin + pr;
   // two independent pixels per trip keep two loads in flight per thread
@@ -228,8 +222,8 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const T* __restrict_
       f1[e] = silu ? silu_t<T>(y1) : y1;
     }
     if constexpr (SPLIT) {
-      store_split4(dst3 + (size_t)p * 3 * C, C, c0, f0);
-      store_split4(dst3 + (size_t)(p + k) * 3 * C, C, c0, f1);
+      store_split4(dst3 + (size_t)p * 2 * C, c0, f0);
+      store_split4(dst3 + (size_t)(p + k) * 2 * C, c0, f1);
     } else {
       *reinterpret_cast<uint4*>(dst + (size_t)p * C) = pack16<T>(f0);
       *reinterpret_cast<uint4*>(dst + (size_t)(p + k) * C) = pack16<T>(f1);
@@ -241,7 +235,7 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const T* __restrict_
     unpack16<T>(v0, f0);
 #pragma unroll
     for (int e = 0; e < EPV; ++e) { const float y0 = f0[e] * A[e] + B[e]; f0[e] = silu ? silu_t<T>(y0) : y0; }
-    if constexpr (SPLIT) store_split4(dst3 + (size_t)p * 3 * C, C, c0, f0);
+    if constexpr (SPLIT) store_split4(dst3 + (size_t)p * 2 * C, c0, f0);
     else *reinterpret_cast<uint4*>(dst + (size_t)p * C) = pack16<T>(f0);
   }
 }
@@ -290,7 +284,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1,
           for (int e = 0; e < EPV; ++e) { const float y = f[e] * A[e] + B[e]; r[e] += 0.25f * (silu ? silu_t<T>(y) : y); }
         }
     }
-    if constexpr (SPLIT) store_split4(reinterpret_cast<f16_t*>(out) + (((size_t)n * ho + yo) * wo + xo) * 3 * C, C, c0, r);
+    if constexpr (SPLIT) store_split4(reinterpret_cast<f16_t*>(out) + (((size_t)n * ho + yo) * wo + xo) * 2 * C, c0, r);
     else *reinterpret_cast<uint4*>(out + (((size_t)n * ho + yo) * wo + xo) * C + c0) = pack16<T>(r);
   }
 }

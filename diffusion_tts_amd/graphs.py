@@ -9,8 +9,9 @@ launches) and replayed with one launch; inputs are copied into the captured inpu
 Not a tracing compiler: nothing is rewritten or fused, the graph is the eager launch sequence.  The first calls of a shape run
 eagerly (they also perform the one-time `hipFuncSetAttribute` calls), the third is captured; a module stops capturing new
 shapes after 8 captures (MCTS rollouts change their batch size all the time).  `DTS_GRAPHS=0` disables it.
-`DTS_GRAPHS_STRICT=1` (set by bench.py) turns a refused capture into an error instead of a silent return to eager launches: a
-measurement must not report eager-launch numbers under the graph-replay name."""
+A refused capture is an ERROR (the product must not run 3-5x slower at small batches behind a Python warning, and a measurement must
+not report eager-launch numbers under the graph-replay name); `DTS_GRAPHS_STRICT=0` opts into the eager fallback explicitly, and then
+`GraphCache.fallback` records why.  `path_report()` says which path a module's forwards took (main.py prints it)."""
 import gc
 import os
 import warnings
@@ -36,6 +37,8 @@ class GraphCache:
         self.graphs = OrderedDict()
         self.replays = 0
         self.captures = 0
+        self.eager = 0                  # forwards launched kernel by kernel (first sightings of a shape, shapes beyond MAX_CAPTURES, graphs off)
+        self.fallback = None            # why capturing stopped (only with DTS_GRAPHS_STRICT=0)
 
     @property
     def fn(self):
@@ -47,15 +50,18 @@ class GraphCache:
     def __call__(self, *inputs):
         """inputs: device tensors (or None); returns a tensor the caller owns."""
         if not self.enabled:
+            self.eager += 1
             return self.fn(*inputs)
         key = tuple(None if t is None else (tuple(t.shape), t.dtype, t.device.index) for t in inputs)
         ent = self.graphs.get(key)
         if ent is None:
             self.seen[key] = self.seen.get(key, 0) + 1
             if self.seen[key] < SIGHTINGS or self.captures >= MAX_CAPTURES:
+                self.eager += 1
                 return self.fn(*inputs)
             ent = self._capture(key, inputs)
             if ent is None:
+                self.eager += 1
                 return self.fn(*inputs)
         graph, static_in, static_out = ent
         for s, t in zip(static_in, inputs):
@@ -79,10 +85,12 @@ class GraphCache:
             with torch.cuda.graph(graph):
                 static_out = fn(*static_in)
         except Exception as e:                       # capture refused: stay on the eager launch sequence (same kernels)
-            if os.environ.get('DTS_GRAPHS_STRICT', '0') == '1':
-                raise RuntimeError(f'HIP-graph capture failed under DTS_GRAPHS_STRICT=1 ({type(e).__name__}: {e})') from e
-            warnings.warn(f'HIP-graph capture failed ({type(e).__name__}: {e}); continuing with eager launches')
+            if os.environ.get('DTS_GRAPHS_STRICT', '1') != '0':
+                raise RuntimeError(f'HIP-graph capture failed ({type(e).__name__}: {e}); set DTS_GRAPHS_STRICT=0 to continue with eager '
+                                   f'launches (same kernels, several times slower at small batches) or DTS_GRAPHS=0 to never capture') from e
+            warnings.warn(f'HIP-graph capture failed ({type(e).__name__}: {e}); DTS_GRAPHS_STRICT=0: continuing with eager launches')
             self.enabled = False
+            self.fallback = f'{type(e).__name__}: {e}'
             return None
         finally:
             if gc_was_on:
@@ -92,3 +100,9 @@ class GraphCache:
             self.graphs.popitem(last=False)
         self.graphs[key] = (graph, static_in, static_out)
         return self.graphs[key]
+
+    def path_report(self):
+        """which path this module's forwards took so far"""
+        how = 'HIP-graph replay' if self.replays else ('eager launches' if self.eager else 'no forward yet')
+        extra = f'; capture refused: {self.fallback}' if self.fallback else ('' if self.enabled else '; graphs disabled')
+        return f'{how} ({self.replays} replays of {self.captures} captured graphs, {self.eager} eager forwards{extra})'

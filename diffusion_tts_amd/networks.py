@@ -7,7 +7,9 @@ Parameters are taken from a flat state dict with the reference's own key names
 ('model.enc.64x64_block0.conv0.weight', ...), so a state dict exported from a reference module loads as is.
 
 Every tensor op below is a libdts_hip kernel (ops.py); PyTorch only owns the memory and the stream.
-Activations are NHWC in `dtype` (float32 = parity mode, bfloat16/float16 = throughput modes).
+Activations are NHWC in `dtype`.  Compute modes: ops.F16X3 (DEFAULT: split precision on the 16-bit matrix cores, the reference's fp32
+results -- same selected candidates as the reference's fp32 run, networks.py:658 on a CPU), float32 (parity mode on the f32 matrix
+instruction), bfloat16 / float16 (throughput modes: another sample after the first near-tied pick).
 
 Per UNetBlock (networks.py:166-187) the launch sequence is
   gn_coef+gn_apply(SiLU, [2x2 pool]) -> conv0 [fused nearest-up gather] -> gn_coef(+scale/shift)+gn_apply(SiLU)
@@ -41,7 +43,7 @@ class _BlockParams:
 class EDMPrecond:
     """EDMPrecond + DhariwalUNet / SongUNet(DDPM++) forward on MI355X."""
 
-    def __init__(self, cfg: EDMConfig, state_dict: Dict[str, torch.Tensor], device='cuda', dtype=torch.bfloat16):
+    def __init__(self, cfg: EDMConfig, state_dict: Dict[str, torch.Tensor], device='cuda', dtype=ops.F16X3):
         if not torch.cuda.is_available():
             raise RuntimeError('EDMPrecond (HIP) needs a GPU: there is no CPU fallback in this package')
         self.cfg = cfg
@@ -202,7 +204,7 @@ class EDMPrecond:
             fx3 = self.x3 and ops.attention_x3_ok(hh * ww, c // b.heads)
             qkv = ops.conv2d(hn, P.wqkv, P.bqkv, out_split2=fx3)
             a = ops.attention(qkv.view(n, hh * ww, 3 * c), b.heads, 1.0 / math.sqrt(c // b.heads), x3=self.x3, split_out=fx3)
-            a = ops.SplitAct(a.data.view(n, hh, ww, 3 * c), c) if fx3 else a.view(n, hh, ww, c)
+            a = ops.SplitAct(a.data.view(n, hh, ww, 2 * c), c) if fx3 else a.view(n, hh, ww, c)
             x = ops.conv2d(a, P.wproj, P.bproj, residual=x, out_scale=self.skip_scale, gn_stats=True)
         return x
 

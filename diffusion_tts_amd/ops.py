@@ -14,10 +14,11 @@ from . import _lib as L
 
 _DT = {torch.float32: L.DTS_F32, torch.bfloat16: L.DTS_BF16, torch.float16: L.DTS_F16}
 
-# The split-precision compute mode (dts.h DTS_F16X3): activations are float32 tensors and every kernel but the convolutions is the
-# float32 (parity-mode) one; the convolutions -- 99.9 % of the FLOPs -- run on the 16-bit matrix cores over the f16 split image of
-# their input (hi | lo | hi) against weights packed as hi | hi | lo, f32 accumulate: ~2^-22 products instead of f16's 2^-11, at a
-# third of the f16 rate instead of the f32 matrix instruction's sixteenth.  Accepted wherever a compute dtype is.
+# The split-precision compute mode (dts.h DTS_F16X3), the DEFAULT of every surface that takes a compute dtype: activations are float32
+# tensors and every kernel but the convolutions (and the d = 64 attention) is the float32 (parity-mode) one; the convolutions -- 99.9 % of
+# the FLOPs -- run on the 16-bit matrix cores over the f16 split image of their input (per 32 channels: hi | lo * 2^11) against weights
+# packed per 32 input channels as hi | lo, three MFMAs per staged K step (hi.hi, lo.hi, hi.lo), f32 accumulate: ~2^-22 products instead
+# of f16's 2^-11, at a third of the f16 rate instead of the f32 matrix instruction's sixteenth.
 F16X3 = 'f16x3'
 
 
@@ -31,9 +32,10 @@ def dtype_name(dtype):
 
 
 class X3Weight:
-    """A conv weight packed for the split-precision mode: `packed` [O][kh][kw][3*I] float16 = hi | hi * 2^-11 | lo of w * 2^k along the
-    input channels (k chosen per layer so that 2^13 < max|w| * 2^k <= 2^14: the lo parts of all weights that matter are normal f16
-    numbers; the matrix cores flush subnormal inputs), `acc_scale` = 2^-k.  The middle segment meets the activations' lo * 2^11 plane."""
+    """A conv weight packed for the split-precision mode: `packed` [O][kh][kw][2*I] float16 = per 32 input channels hi(32) | lo(32) of
+    w * 2^k (k chosen per layer so that 2^13 < max|w| * 2^k <= 2^14: the lo parts of all weights that matter are normal f16 numbers;
+    the matrix cores flush subnormal inputs), `acc_scale` = 2^-k.  The kernels scale the hi fragment by 2^-11 in registers where it meets
+    the activations' lo * 2^11 half."""
 
     def __init__(self, packed, acc_scale, shape):
         self.packed, self.acc_scale, self.shape = packed, float(acc_scale), tuple(shape)
@@ -62,15 +64,25 @@ class SplitQKV:
 
 
 class SplitAct:
-    """An activation already in the split-precision operand form: `data` float16 [n,h,w,3*C] = hi | lo * 2^11 | hi (dts_split3_f16 /
-    dts_gn_apply_x3); `shape` is the logical NHWC shape.  Only convolutions with an X3Weight read it."""
+    """An activation already in the split-precision operand form: `data` float16 [n,h,w,2*C], per 32 channels hi(32) | lo * 2^11 (32)
+    (dts_split3_f16 / dts_gn_apply_x3 / dts_attention_x3); `shape` is the logical NHWC shape.  Only convolutions with an X3Weight read it."""
 
     def __init__(self, data, c):
         self.data, self.shape = data, tuple(data.shape[:3]) + (c,)
         self.device, self.dtype = data.device, torch.float32
 
     def numel(self):
-        return self.data.numel() // 3
+        return self.data.numel() // 2
+
+    def planes(self):
+        """(hi, lo * 2^11) as two float16 tensors of the logical shape (tests / debugging)"""
+        return split_planes(self.data, self.shape[-1])
+
+
+def split_planes(data, c):
+    """the two halves of a split-precision operand image `data` [..., 2*c] as tensors [..., c]: (hi, lo * 2^11)"""
+    v = data.reshape(*data.shape[:-1], c // 32, 2, 32)
+    return v[..., 0, :].reshape(*data.shape[:-1], c), v[..., 1, :].reshape(*data.shape[:-1], c)
 
 
 def dt_code(dtype):
@@ -146,10 +158,12 @@ def pack_conv_weight(w, dtype, out_perm=None):
         amax = float(wp.abs().max())
         k = 0 if amax == 0.0 else max(-24, min(24, int(math.floor(math.log2(16384.0 / amax)))))
         ws = (wp * (2.0 ** k)).permute(0, 2, 3, 1).contiguous()            # [O][kh][kw][I], exact (power of two)
+        if I % 32:
+            raise ValueError(f'pack_conv_weight(F16X3): {I} input channels are not a multiple of 32 (one K step of the split image)')
         hi = ws.to(torch.float16)
         lo = (ws - hi.to(torch.float32)).to(torch.float16)
-        hi_s = (hi.to(torch.float32) * 2.0 ** -11).to(torch.float16)       # meets the activations' lo plane, which carries lo * 2^11 (dts_split3_f16)
-        return X3Weight(torch.cat([hi, hi_s, lo], dim=-1).contiguous(), 2.0 ** -k, (O, kh, kw, I))
+        packed = torch.stack([hi.view(O, kh, kw, I // 32, 32), lo.view(O, kh, kw, I // 32, 32)], dim=-2)      # [.., I/32, 2, 32]: hi(32) | lo(32)
+        return X3Weight(packed.reshape(O, kh, kw, 2 * I).contiguous(), 2.0 ** -k, (O, kh, kw, I))
     out = torch.empty((O, kh, kw, I), dtype=dtype, device=w.device)
     _call('dts_pack_conv_weight', _ptr(w, 'w', torch.float32), _ptr(out), dt_code(dtype), O, I, kh, kw,
           _ptr(out_perm, 'perm', torch.int32))
@@ -182,8 +196,8 @@ def conv_kernel(x1, w, x2=None, up=False, residual=None, gn_coef=None):
     """Which kernel ops.conv2d launches for these arguments: 0 = 4-wave implicit GEMM, 6 / 4 = ping-pong kernel with 192- / 128-cout
     blocks (dts_conv_kernel; measurement aid for bench.py)."""
     a = _conv_args(x1, w, x2, up)
-    if isinstance(w, X3Weight):           # the launch sees one 16-bit source of 3*(c1+c2) channels
-        a.c1, a.c2, a.dtype = 3 * (a.c1 + a.c2), 0, L.DTS_F16X3
+    if isinstance(w, X3Weight):           # the launch sees one 16-bit source of 2*(c1+c2) channels
+        a.c1, a.c2, a.dtype = 2 * (a.c1 + a.c2), 0, L.DTS_F16X3
     a.residual = _ptr(residual)
     a.gn_coef = _ptr(gn_coef, 'gn_coef', torch.float32)
     return int(L.load().dts_conv_kernel(C.byref(a)))
@@ -220,9 +234,9 @@ def conv2d(x1, w, bias=None, *, x2=None, bias_nc=None, residual=None, up=False, 
     a = L.ConvArgs()
     a.out_split2 = int(out_split2)
     dt_in = x1.dtype
-    if x3:      # the conv reads the f16 split image hi | lo | hi of concat(x1, x2); epilogue operands and output stay float32
+    if x3:      # the conv reads the f16 split image (per 32 channels hi | lo) of concat(x1, x2); epilogue operands and output stay float32
         xs = x1.data if isinstance(x1, SplitAct) else split3_f16(x1, x2)
-        a.x1, a.c1, a.x2, a.c2 = _ptr(xs, 'x1', torch.float16), 3 * (c1 + c2), None, 0
+        a.x1, a.c1, a.x2, a.c2 = _ptr(xs, 'x1', torch.float16), 2 * (c1 + c2), None, 0
         a.w, a.acc_scale = _ptr(w.packed, 'w', torch.float16), w.acc_scale
     else:
         a.x1, a.c1 = _ptr(x1, 'x1'), c1
@@ -256,10 +270,11 @@ def conv2d(x1, w, bias=None, *, x2=None, bias_nc=None, residual=None, up=False, 
 
 
 def split3_f16(x1, x2=None):
-    """float32 NHWC [n,h,w,c1] (+ [n,h,w,c2]) -> float16 [n,h,w,3*(c1+c2)] = hi | lo | hi of the channel concat (dts_split3_f16)."""
+    """float32 NHWC [n,h,w,c1] (+ [n,h,w,c2]) -> float16 [n,h,w,2*(c1+c2)]: per 32 channels of the channel concat hi(32) | lo * 2^11 (32)
+    (dts_split3_f16; the historical name: round 4's image had three planes)."""
     n, h, w, c1 = x1.shape
     c2 = 0 if x2 is None else x2.shape[-1]
-    out = torch.empty((n, h, w, 3 * (c1 + c2)), dtype=torch.float16, device=x1.device)
+    out = torch.empty((n, h, w, 2 * (c1 + c2)), dtype=torch.float16, device=x1.device)
     _call('dts_split3_f16', _ptr(x1, 'x1', torch.float32), c1, _ptr(x2, 'x2', torch.float32), c2, _ptr(out), n * h * w)
     return out
 
@@ -303,7 +318,7 @@ def gn_apply(x1, coef, *, x2=None, silu=True, pool=False, split_out=False):
     c2 = 0 if x2 is None else x2.shape[-1]
     ho, wo = (h // 2, w // 2) if pool else (h, w)
     if split_out:
-        out = torch.empty((n, ho, wo, 3 * (c1 + c2)), dtype=torch.float16, device=x1.device)
+        out = torch.empty((n, ho, wo, 2 * (c1 + c2)), dtype=torch.float16, device=x1.device)
         _call('dts_gn_apply_x3', _ptr(x1, 'x1', torch.float32), c1, _ptr(x2, 'x2', torch.float32), c2, _ptr(coef, 'coef', torch.float32),
               _ptr(out), n, h, w, int(silu), int(pool))
         return SplitAct(out, c1 + c2)
@@ -392,9 +407,9 @@ def attention(qkv, heads, scale, x3=False, split_out=False):
             sp = torch.empty((n, t, 2 * c3), dtype=torch.float16, device=qkv.device)
             _call('dts_split2_f16', _ptr(qkv, 'qkv', torch.float32), c3, _ptr(sp), n * t)
         if split_out:
-            out = torch.empty((n, t, 3 * c), dtype=torch.float16, device=qkv.device)
+            out = torch.empty((n, t, 2 * c), dtype=torch.float16, device=qkv.device)
             _call('dts_attention_x3', _ptr(sp), _ptr(out), 1, n, t, heads, d, float(scale))
-            return SplitAct(out.view(n, t, 1, 3 * c), c)
+            return SplitAct(out.view(n, t, 1, 2 * c), c)
         out = torch.empty((n, t, c), dtype=torch.float32, device=qkv.device)
         _call('dts_attention_x3', _ptr(sp), _ptr(out), 0, n, t, heads, d, float(scale))
         return out
@@ -580,6 +595,16 @@ def candidate_noise(pivot, g, mode, scale):
     out = torch.empty_like(g)
     _call('dts_candidate_noise', _ptr(pivot, 'pivot', torch.float64), _ptr(g, 'g', torch.float64),
           _ptr(mode, 'mode', torch.int32), _ptr(scale, 'scale', torch.float32), _ptr(out), nb, b, pivot[0].numel())
+    return out
+
+
+def candidate_noise_sd(pivot, u, mode, scale):
+    """pivot [1,C,H,W], u [N,1,C,H,W] (same dtype), mode int32 [N], scale f32 [N] -> candidates [N,1,C,H,W]: the SD backend's
+    eps-greedy / zero-order builder (pipeline_stable_diffusion.py:1371-1379) in the latents' dtype."""
+    n = u.shape[0]
+    out = torch.empty_like(u)
+    _call('dts_candidate_noise_sd', _ptr(pivot, 'pivot'), _ptr(u, 'u', pivot.dtype), _ptr(mode, 'mode', torch.int32),
+          _ptr(scale, 'scale', torch.float32), _ptr(out), dt_code(pivot.dtype), n, pivot.numel())
     return out
 
 

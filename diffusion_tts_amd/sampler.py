@@ -46,7 +46,7 @@ class SamplingParams:                # edm/main.py:35-43
     scorer: Scorer = field(default_factory=lambda: CompressibilityScorer(dtype=torch.float32))
 
 
-def load_network(spec, device='cuda', dtype=torch.bfloat16):
+def load_network(spec, device='cuda', dtype=ops.F16X3):
     """`network_pkl` argument of generate_image_grid.  The reference unpickles an NVIDIA EDM checkpoint from a URL
     (edm/main.py:69-70); URLs cannot be fetched here, so accepted forms are: a ready network object; the local path of
     an EDM network pickle (`*.pkl`, read by checkpoint.load_edm_pickle without executing its embedded source); a
@@ -430,11 +430,12 @@ def generate_image_grid(
     sampling_method: SamplingMethod = SamplingMethod.NAIVE,
     sampling_params: Optional[Dict[str, Any]] = None,
     precomputed_noise: Optional[Dict[Any, torch.Tensor]] = None,
-    *, scale_fn: Callable[[int, int, int], float] = builtin_scale, compute_dtype=torch.bfloat16, verbose=True,
+    *, scale_fn: Callable[[int, int, int], float] = builtin_scale, compute_dtype=ops.F16X3, verbose=True,
     reuse_winner: Optional[bool] = None, record_noises: bool = False, shard_candidates: bool = True,
 ):
     """Same positional/keyword surface as edm/main.py:47-55.  Keyword-only extras: `scale_fn` (the hash-derived step
-    table, edm/main.py:776), `compute_dtype` (float32 = parity mode), `verbose`, `reuse_winner` (see below), `record_noises`
+    table, edm/main.py:776), `compute_dtype` (default ops.F16X3: split precision, the reference's fp32 selections at a third of the 16-bit
+    rate; float32 = parity mode on the f32 matrix instruction; bfloat16 / float16 = throughput modes), `verbose`, `reuse_winner` (see below), `record_noises`
     (keep the per-iteration winning noises for `dump_noise_trajectory`; costs one D2H copy per iteration).  Writes the PNG grid like the
     reference when `dest_path` is not None and additionally returns a dict with the final state and the search trace."""
     device = torch.device(device)
@@ -451,7 +452,8 @@ def generate_image_grid(
     t_steps = torch.cat([net.round_sigma(t_steps), torch.zeros_like(t_steps[:1])])
     L = _Loop(net, device, num_steps, S_churn, S_min, S_max, S_noise, scale_fn, shards)
     # eps-greedy: the reference re-runs step() at batch 1 for the final pivot of each timestep (edm/main.py:860) although
-    # that row was just computed in the last candidate batch.  Throughput modes reuse it; parity mode recomputes.
+    # that row was just computed in the last candidate batch.  The default mode (f16x3) and float32 recompute it like the reference, so
+    # `net_rows` equals the reference's count (config 3: 8 995); the 16-bit throughput modes reuse the row (8 960 rows, same values).
     L.reuse_winner = (compute_dtype not in (torch.float32, ops.F16X3)) if reuse_winner is None else bool(reuse_winner)
     L.record_noises = bool(record_noises)
     x0 = (latents.to(torch.float64).cpu() * t_steps[0]).to(device).contiguous()       # edm/main.py:99

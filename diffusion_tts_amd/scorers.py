@@ -73,8 +73,9 @@ class ImageNetScorer(Scorer):
     CACHE = os.path.expanduser('~/.cache/imagenet_classifier/64x64_classifier.pt')
 
     def __init__(self, dtype=torch.float32, weights=None, cfg: ClassifierConfig = None, seed=1, device='cuda',
-                 compute_dtype=torch.float16):
-        """compute_dtype: the classifier's activation / weight type.  float16 by default even beside a bfloat16 denoiser: the reward
+                 compute_dtype=ops.F16X3):
+        """compute_dtype: the classifier's activation / weight type.  Default ops.F16X3 (split precision: the reference scores in fp32,
+        main.py:69, and the search's argmax is taken on these rewards, edm/main.py:842).  Beside a bfloat16 denoiser use float16: the reward
         error of a 16-bit search iteration is the CLASSIFIER's (measured, tools/dtype_mix.py: bf16 scorer 2.0e-6 whatever the
         denoiser's type; f16 scorer 2.2e-7 ... 4.4e-7), the classifier is 8 % of an iteration's FLOPs, and float16 is what the
         reference's networks use on a GPU (edm/training/networks.py:658); bfloat16 is accepted, float32 is the parity mode."""

@@ -350,23 +350,29 @@ class SDSearchPipeline:
                     N = params['N']
                     self.shards.require_candidates(N, 'SD eps-greedy / zero-order search')
                     thr = params['eps'] if method == 'eps_greedy' else 0.0
+                    pivot_d = self._up(pivot, dtype)
                     for _ in range(params['K']):
-                        cands = []
+                        # host RNG in the reference's call order (:1371-1379): the coin, the Gaussian, the step length; the candidate
+                        # ARITHMETIC (normalise, scale, add the pivot) runs on the device in the latents' dtype (dts_candidate_noise_sd)
+                        draws, mode, scale = [], [], []
                         for _ in range(N):
                             r = torch.rand(1).item()
                             if r < thr:
-                                cands.append(randn())
+                                draws.append(randn())
+                                mode.append(0)
+                                scale.append(0.0)
                             else:
-                                u = randn()
-                                u = u / torch.norm(u)
-                                cands.append(pivot + u * torch.rand(1).item() * params['lambda'] *
-                                             np.sqrt(shape[-1] * shape[-2] * shape[-3]))
+                                draws.append(randn())
+                                mode.append(1)
+                                scale.append(torch.rand(1).item() * params['lambda'] * np.sqrt(shape[-1] * shape[-2] * shape[-3]))
                         for _ in range(N):
                             randn()                                            # dropped variance noise (:1410)
-                        _, vals = self._evaluate(noise_pred, t, latents, self._up(torch.stack(cands), dtype), eu, ec, g, eta,
-                                                 score_function, prompt, scores)
+                        cands = ops.candidate_noise_sd(pivot_d, self._up(torch.stack(draws), dtype), torch.tensor(mode, dtype=torch.int32, device=dev),
+                                                       torch.tensor(scale, dtype=torch.float32, device=dev))
+                        _, vals = self._evaluate(noise_pred, t, latents, cands, eu, ec, g, eta, score_function, prompt, scores)
                         max_score = max(vals)
-                        pivot = cands[vals.index(max_score)]                   # first max (:1432-1433)
+                        pivot_d = cands[vals.index(max_score)].contiguous()    # first max (:1432-1433)
+                    pivot = pivot_d
                 latents, _ = sch.step(noise_pred, t, latents, eta, variance_noise=self._up(pivot, dtype))
         image = self.vae.decode(latents / self.vae.config.scaling_factor, return_dict=False)[0]
         if max_score is None:

@@ -28,20 +28,24 @@ extern "C" {
 typedef void* dts_stream;
 
 enum dts_dtype { DTS_F32 = 0, DTS_BF16 = 1, DTS_F16 = 2,
-                 /* dts_conv2d only: SPLIT PRECISION on the 16-bit matrix cores.  Activations and the epilogue operands (bias_nc, residual,
-                    out) are f32 tensors; the conv's input is their split image from dts_split3_f16 -- x1 = [n][h][w][3*C] f16 holding
-                    hi | lo * 2^11 | hi with hi = f16(x), lo = x - hi -- and the packed weight is [cout][taps][3*C] f16 =
-                    hi | hi * 2^-11 | lo of w * 2^k (acc_scale = 2^-k; the powers of two keep every part a NORMAL f16 number: the matrix
-                    cores flush subnormal inputs), so ONE 16-bit MFMA K loop of three times the length accumulates, in f32,
-                    x_hi*w_hi + x_lo*w_hi + x_hi*w_lo: products exact to ~2^-22 (f16 x f16 carries 22 bits) against 2^-24 of the f32
-                    matrix instruction, which runs at 1/16 of the 16-bit rate.  The mode between the f32 parity mode and the 16-bit
-                    throughput modes (edm/main.py:842 argmax over rewards that differ by 1e-7). */
+                 /* dts_conv2d only: SPLIT PRECISION on the 16-bit matrix cores -- the DEFAULT compute mode of the Python surfaces.  Activations
+                    and the epilogue operands (bias_nc, residual, out) are f32 tensors; the conv's input is their split image from
+                    dts_split3_f16 -- x1 = [n][h][w][2*C] f16, per group of 32 channels 128 bytes = hi(32) | lo * 2^11 (32) with hi = f16(x),
+                    lo = x - hi (pass c1 = 2*C, c2 = 0) -- and the packed weight is [cout][taps][2*C] f16, per 32 input channels
+                    wh(32) | wl(32) = the hi / lo parts of w * 2^k (acc_scale = 2^-k; the powers of two keep every part a NORMAL f16 number:
+                    the matrix cores flush subnormal inputs).  One staged 128-byte K step feeds THREE MFMAs per accumulator tile --
+                    wh.hi, (wh * 2^-11).(lo * 2^11), wl.hi -- accumulating, in f32, x_hi*w_hi + x_lo*w_hi + x_hi*w_lo: products exact to
+                    ~2^-22 (f16 x f16 carries 22 bits) against 2^-24 of the f32 matrix instruction, which runs at 1/16 of the 16-bit
+                    rate.  This is the mode that reproduces the reference's fp32 selections (edm/main.py:842: argmax over rewards that
+                    differ by 1e-7) at a third of the 16-bit modes' matrix rate.  (ABI 108 laid the image out as three planes hi | lo | hi
+                    against hi | hi * 2^-11 | lo: 1.5 x the bytes, LDS-DMA pieces and fragment reads for the same products.) */
                  DTS_F16X3 = 3 };
 enum dts_status { DTS_OK = 0, DTS_ERR_ARG = -1, DTS_ERR_LAUNCH = -2, DTS_ERR_UNSUPPORTED = -3 };
 
-#define DTS_ABI_VERSION 108        /* bumped with every change of a signature or of dts_conv_args (101: ev_start/ev_stop; 102: tuning knobs; 103: dts_cosine_rows; 104: dts_nchw_to_nhwc_pad,
+#define DTS_ABI_VERSION 109        /* bumped with every change of a signature or of dts_conv_args (101: ev_start/ev_stop; 102: tuning knobs; 103: dts_cosine_rows; 104: dts_nchw_to_nhwc_pad,
                                      105: dts_conv_args.gn_coef / gn_silu, dts_conv_fuses_gn;
-                                     head dim 512 in dts_attention; 106: dts_conv_kernel, 128-cout ping-pong blocks; 107: dts_resample_u8, dts_lut_u8_f32; 108: DTS_F16X3, dts_conv_args.acc_scale, dts_split3_f16, dts_gn_apply_x3, dts_split2_f16, dts_attention_x3) */
+                                     head dim 512 in dts_attention; 106: dts_conv_kernel, 128-cout ping-pong blocks; 107: dts_resample_u8, dts_lut_u8_f32; 108: DTS_F16X3, dts_conv_args.acc_scale, dts_split3_f16, dts_gn_apply_x3, dts_split2_f16, dts_attention_x3;
+                                     109: dts_candidate_noise_sd; the DTS_F16X3 operand images are 2*C wide, interleaved per 32 channels) */
 int dts_version(void);            /* == DTS_ABI_VERSION of the build; a binding must refuse any other value */
 const char* dts_last_error(void);
 /* Tuning knobs (measurement aid; a knob only selects between kernels / block orders / ring depths that give correct results -- the
@@ -93,7 +97,7 @@ typedef struct dts_conv_args {
   int32_t gn_silu;                /* 1: act = SiLU, 0: identity */
   float acc_scale;                /* DTS_F16X3 only (0 = 1): out = (conv * acc_scale + bias + bias_nc + residual) * out_scale; undoes the power of
                                      two the packed split-precision weights carry */
-  int32_t out_split2;             /* DTS_F16X3 only: 1 = `out` is f16 [n][hout][wout][2*cout] = hi(cout) | lo(cout) of the result * 2^6 per pixel (the
+  int32_t out_split2;             /* DTS_F16X3 only: 1 = `out` is f16 [n][hout][wout][2*cout] = hi(cout) | lo(cout) of the result * 2^6 per pixel, saturating (the
                                      image dts_split2_f16 would make of it: the qkv projection feeding dts_attention_x3) instead of f32 [..][cout] */
 } dts_conv_args;
 /* 1 if dts_conv2d would apply a->gn_coef inside the conv for this shape / dtype (3x3, cout % 192 == 0, 16-bit, square power-of-two
@@ -129,8 +133,9 @@ int dts_gn_coef_strips(const float* st1, int c1, const float* st2, int c2, int d
  * networks.py:84-85; unet.py:213-215 avg_pool) and writes [n][h/2][w/2][C]. */
 int dts_gn_apply(const void* x1, int c1, const void* x2, int c2, int dtype, const float* coef,
                  void* out, int n, int h, int w, int silu, int pool, dts_stream s);
-/* the same pass in the split-precision mode (DTS_F16X3): x / coef as above in f32, out = the f16 split image [n][h'][w'][3*C] (hi | lo * 2^11 |
- * hi, the arithmetic of dts_split3_f16) that dts_conv2d(dtype = DTS_F16X3) reads -- the f32 normalised tensor is never written. */
+/* the same pass in the split-precision mode (DTS_F16X3): x / coef as above in f32, out = the f16 split image [n][h'][w'][2*C] (per 32
+ * channels hi | lo * 2^11, the arithmetic and layout of dts_split3_f16) that dts_conv2d(dtype = DTS_F16X3) reads -- the f32 normalised
+ * tensor is never written.  C a multiple of 32. */
 int dts_gn_apply_x3(const float* x1, int c1, const float* x2, int c2, const float* coef, void* out, int n, int h, int w, int silu,
                     int pool, dts_stream s);
 /* single-launch variant for low-resolution levels (hw <= ~256): statistics + apply in one kernel, one block per
@@ -146,7 +151,7 @@ int dts_resample2x(const void* x, void* out, int dtype, int n, int h, int w, int
 int dts_attention(const void* qkv, void* out, int dtype, int n, int t, int heads, int d, float scale, dts_stream s);
 /* the same attention in the split-precision mode (DTS_F16X3; d = 64): qkv_split = dts_split2_f16 of the f32 qkv tensor, f16 [n][t][6*heads*d] =
  * hi(3C) | lo(3C) per token (also what dts_conv2d writes with out_split2); out f32 [n][t][heads*d], or with out_split3 = 1 the f16 operand
- * image [n][t][3*heads*d] (hi | lo * 2^11 | hi, dts_split3_f16's arithmetic) the proj convolution reads.  Q.K^T and P.V on the 16-bit matrix cores with hi/lo operand pairs (the lo*lo term,
+ * image [n][t][2*heads*d] (per 32 channels hi | lo * 2^11: dts_split3_f16's arithmetic and layout) the proj convolution reads.  Q.K^T and P.V on the 16-bit matrix cores with hi/lo operand pairs (the lo*lo term,
  * 2^-22, dropped), softmax in f32: the f32 kernel's accuracy without the f32 matrix instruction's 1/16 rate. */
 int dts_attention_x3(const void* qkv_split, void* out, int out_split3, int n, int t, int heads, int d, float scale, dts_stream s);
 
@@ -161,11 +166,11 @@ int dts_edm_precond_in(const double* x, const double* sigma, int nsigma, float s
                        float* xin, float* coef, int n, int chw, dts_stream s);
 /* D = c_skip*f32(x) + c_out*F  (f32, NCHW) */
 int dts_edm_precond_out(const double* x, const float* F, const float* coef, float* D, int n, int chw, dts_stream s);
-/* split-precision operand image for dts_conv2d(dtype = DTS_F16X3): out[p][0:C] = hi, [C:2C] = lo * 2^11, [2C:3C] = hi of
- * concat(x1, x2)[p][:] (f32 rows of c1 / c2 channels, x2 may be NULL with c2 = 0; C = c1 + c2, multiples of 8), hi = f16(x) (0 when that
- * would be subnormal), lo = f16((x - hi) * 2^11). */
+/* split-precision operand image for dts_conv2d(dtype = DTS_F16X3): row p of concat(x1, x2) (f32 rows of c1 / c2 channels, x2 may be NULL
+ * with c2 = 0; c1, c2 multiples of 8, C = c1 + c2 a multiple of 32) -> out[p][64*g + j] = hi, out[p][64*g + 32 + j] = lo * 2^11 of channel
+ * 32*g + j: hi = f16(x) (0 when that would be subnormal; +-65504 beyond the f16 range), lo = f16((x - hi) * 2^11).  out: f16 [rows][2*C]. */
 int dts_split3_f16(const float* x1, int c1, const float* x2, int c2, void* out, int64_t rows, dts_stream s);
-/* out[p][0:c] = hi, [c:2c] = lo of x[p][:] * 2^6 (hi = f16(y), lo = f16(y - hi); |x| < 1023): the operand image of dts_attention_x3 */
+/* out[p][0:c] = hi, [c:2c] = lo of x[p][:] * 2^6 (hi = f16(y), lo = f16(y - hi); |y| saturates at 65504, i.e. |x| at 1023.5): the operand image of dts_attention_x3 */
 int dts_split2_f16(const float* x, int c, void* out, int64_t rows, dts_stream s);
 /* f32 -> dtype cast of a dense array (embedding -> activation dtype) and back */
 int dts_cast_from_f32(const float* src, void* dst, int dtype, int64_t count, dts_stream s);
@@ -217,6 +222,11 @@ int dts_softmax_gather(const float* logits, const int32_t* target, float* reward
  *   mode[n] == 1 : cand[i] = pivot[i % b] + (double)scale[n] * (g[i] / ||g[i]||_2)   (edm/main.py:767-788) */
 int dts_candidate_noise(const double* pivot, const double* g, const int32_t* mode, const float* scale,
                         double* cand, int nb, int b, int chw, dts_stream s);
+/* The SD backend's builder (sd/diffusers/.../pipeline_stable_diffusion.py:1371-1379), in the latents' storage type `dtype` with the
+ * reference's roundings: u host-drawn normals [n][count]; mode[c] == 0: cand[c] = u[c] (fresh noise, :1375);
+ * mode[c] == 1: cand[c] = pivot + (u[c] / ||u[c]||) * scale[c], scale = rand * lambda * sqrt(count) (:1377-1379).  pivot [count]. */
+int dts_candidate_noise_sd(const void* pivot, const void* u, const int32_t* mode, const float* scale, void* cand, int dtype, int n,
+                           int64_t count, dts_stream s);
 
 /* ---- K13: DDIM candidate step, SD backend (scheduling_ddim.py:402-463), eta*std = sigma_t ---------- */
 /* For i in [0,count): x0 = (x - sqrt(1-a_t) e)/sqrt(a_t); [e' = (x - sqrt(a_t) x0)/sqrt(1-a_t) == e];

@@ -11,8 +11,9 @@ Arguments (verbatim from the reference):
 Additions (the reference hard-codes a checkpoint URL, main.py:157-158; there is no network here):
     --network   : 'random:adm_imagenet64[:seed]' (default), 'random:ddpmpp_cifar10[:seed]', the local path of an NVIDIA EDM
                   network pickle (*.pkl, read without executing its embedded source), or a .pt bundle
-    --dtype     : bf16 (default) | f16 | f32 (parity mode, f32 matrix instruction) | f16x3 (split precision on the 16-bit matrix cores:
-                  near-f32 rewards, the reference's selections, ~2.5x the f32 mode's speed)
+    --dtype     : f16x3 (default: split precision on the 16-bit matrix cores -- the reference's fp32 rewards and therefore its selected
+                  candidates on the same seed, ~2.6x the f32 mode's speed) | f32 (parity mode, f32 matrix instruction) | bf16 | f16
+                  (throughput modes: ~2.8x faster again, but a near-tied pick differs after ~10 decisions and the result is another sample)
     --seeds LIST --outdir DIR [--subdirs] [--class N]: bulk mode (flags of the reference's edm/generate.py): one search per
                   seed, <outdir>/<seed:06d>.png; with torch.distributed.run the SEEDS are split over the ranks (no collective)
 Multi-GPU: launch with `python -m torch.distributed.run --nproc-per-node N main.py ...`; the N candidates of every
@@ -128,7 +129,7 @@ def main(argv=None):
     parser.add_argument('--seed', type=int, default=0, help='Random seed')
     parser.add_argument('--device', type=str, default='cuda', help='Device')
     parser.add_argument('--network', type=str, default='random:adm_imagenet64', help='EDM network spec (see module docstring)')
-    parser.add_argument('--dtype', type=str, default='bf16', choices=['bf16', 'f16', 'f32', 'f16x3'], help='compute mode (see the module docstring)')
+    parser.add_argument('--dtype', type=str, default='f16x3', choices=['bf16', 'f16', 'f32', 'f16x3'], help='compute mode (see the module docstring)')
     parser.add_argument('--vae', type=str, default='hip', choices=['hip', 'diffusers'],
                         help="SD backend: 'hip' = this build's VAE decoder (an error if its safetensors cannot be read), 'diffusers' = the stock module")
     parser.add_argument('--seeds', type=str, default=None, help='bulk mode: seeds, e.g. 0-63 or 1,2,5-10 (one image per seed)')
@@ -200,7 +201,8 @@ def main(argv=None):
                               num_steps=18, S_churn=40, S_min=0.05, S_max=50, S_noise=1.003,
                               sampling_method=method_map[args.method], sampling_params=sampling_params, compute_dtype=dtype)
     if int(os.environ.get('RANK', '0')) == 0:
-        print(f'\n[EDM] Saved: {outname}  (denoiser rows: {res["net_rows"]}, reward collectives: {res["collectives"]})\n')
+        print(f'\n[EDM] Saved: {outname}  (denoiser rows: {res["net_rows"]}, reward collectives: {res["collectives"]})')
+        print(f'[EDM] compute mode {args.dtype}; denoiser forwards: {net._graphs.path_report()}\n')
     if world > 1:
         dist.destroy_process_group()
     return res

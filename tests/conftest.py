@@ -23,3 +23,15 @@ def golden():
 def manifest():
     with open(os.path.join(ROOT, 'tests', 'golden', 'manifest.json')) as f:
         return json.load(f)
+
+
+@pytest.fixture(scope='session')
+def golden_full():
+    """outputs of the reference itself at the full BASELINE network sizes (tests/golden/make_golden_fullsize.py)"""
+    return np.load(os.path.join(ROOT, 'tests', 'golden', 'fullsize_golden.npz'))
+
+
+@pytest.fixture(scope='session')
+def manifest_full():
+    with open(os.path.join(ROOT, 'tests', 'golden', 'fullsize_manifest.json')) as f:
+        return json.load(f)

@@ -140,3 +140,19 @@ def synthetic_edm_pickle(cfg, sd, precond='EDMPrecond'):
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def full_weights(manifest_full, which):
+    """(cfg, state dict) of a full-size BASELINE network: the product initialiser + the weight rule, pinned by the checksum the golden
+    generator recorded for the weights it loaded into the REFERENCE module (tests/golden/make_golden_fullsize.py)."""
+    from diffusion_tts_amd.config import adm_imagenet64, ddpmpp_cifar10
+    if which == 'cls_imagenet64':
+        cfg = ClassifierConfig()
+        sd, _ = dinit.refill_degenerate(dinit.classifier_state_dict(cfg, manifest_full['cls_seed']), manifest_full['cls_seed'])
+    else:
+        cfg = {'adm_imagenet64': adm_imagenet64, 'ddpmpp_cifar10': ddpmpp_cifar10}[which]()
+        sd, _ = dinit.refill_degenerate(dinit.edm_state_dict(cfg, manifest_full['net_seed']), manifest_full['net_seed'])
+    ck, ref = dinit.checksum(sd), manifest_full[which]['checksum']
+    assert ck['numel'] == ref['numel'] and abs(ck['abs_sum'] - ref['abs_sum']) < 1e-9 * ref['abs_sum'] \
+        and abs(ck['sum'] - ref['sum']) < 1e-9 * max(1.0, abs(ref['sum'])), (which, ck, ref)
+    return cfg, sd

@@ -28,6 +28,7 @@ def test_launcher_builds_one_rank_per_gpu(monkeypatch):
     assert cmd[-4:] == ['--gpus', '4', '--steps', '3'] and seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
     a = bench.parse([])
     assert (a.gpus, a.scaling, a.candidates, a.workload, a.cpu_sample) == (1, 'strong', 64, 'adm64_eps_greedy', 64)
+    assert a.dtype == 'f16x3'            # the metric of record is measured in the mode that reproduces the reference's selections
 
 
 @pytest.mark.gpu
@@ -44,6 +45,6 @@ def test_two_ranks_started_by_the_bench_itself_shard_the_64_candidates():
     line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(line) == 1, r.stdout
     j = json.loads(line[0])
-    assert j['n_gpus'] == 2 and j['scaling'] == 'strong'
+    assert j['n_gpus'] == 2 and j['scaling'] == 'strong' and j['dtype'] == 'f16x3' and j['config']['parity_grade'] is True
     assert j['config']['candidates_total'] == 64 and j['config']['candidates_per_gpu'] == 32
     assert j['weak_value'] is not None and j['value'] > 0

@@ -25,8 +25,10 @@ def adm():
 X3 = 'f16x3'          # ops.F16X3: split precision on the 16-bit matrix cores; held to the f32 parity mode's tolerances
 
 
-# tolerances = 3 x the measured error (r04: f32 2.3e-7, f16x3 2.1e-7, f16 1.9e-4, bf16 1.5e-3 of max|D|; round 3 asserted 3e-4 / 8e-2)
-@pytest.mark.parametrize('dtype,tol', [(torch.float32, 7e-7), (X3, 7e-7), (torch.float16, 6e-4), (torch.bfloat16, 4.5e-3)])
+# tolerances ~ 10 x the measured error (r04: f32 2.3e-7, f16x3 2.1e-7, f16 1.9e-4, bf16 1.5e-3 of max|D|; the measured value is printed).
+# Headroom for what legitimately moves an f32 summation order by a few ulp: a split-K / launch-form heuristic, FMA contraction of
+# another compiler release; a real regression of a mode is orders of magnitude, not a factor of three.
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 2.5e-6), (X3, 2.5e-6), (torch.float16, 2e-3), (torch.bfloat16, 1.5e-2)])
 def test_adm64_forward_matches_oracle(adm, manifest, dtype, tol):
     from diffusion_tts_amd.networks import EDMPrecond
     cfg, sd = adm
@@ -247,7 +249,7 @@ def test_config3_full_candidate_batch_n64_one_iteration_matches_oracle(adm):
     _, x0_3, r3 = gpu(n3, s3)
     e3 = (r3 - rew_o).abs().max().item()
     print(f'config 3, N=64, f16x3: max reward err {e3:.2e}, argmax {int(r3.argmax())} (oracle {best_o}), max |x0 - x0_oracle| {(x0_3 - x0_o).abs().max().item():.2e}')
-    assert e3 < 5e-8 and gap > 2 * e3 and int(r3.argmax()) == best_o and (x0_3 - x0_o).abs().max().item() < 1e-3
+    assert e3 < 1e-7 and gap > 2 * e3 and int(r3.argmax()) == best_o and (x0_3 - x0_o).abs().max().item() < 1e-3
     del n3, s3
     for dt in (torch.float16, torch.bfloat16):                      # throughput modes: same inputs; agreement is reported, bounded loosely
         n16, s16, _, _ = _adm_and_scorers(adm, dt)
@@ -290,7 +292,7 @@ def test_config3_whole_search_index_agreement_teacher_forced(adm):
     r3 = rec['f16x3']
     a3, n3 = map(int, r3['agree_decidable'].split('/'))
     assert n3 >= 36 and a3 == n3, r3
-    assert int(r3['agree'].split('/')[0]) >= 68 and r3['max_reward_dev_vs_f32'] < 5e-8 and r3['max_regret'] <= 1e-8, r3
+    assert int(r3['agree'].split('/')[0]) >= 68 and r3['max_reward_dev_vs_f32'] < 1e-7 and r3['max_regret'] <= 1e-8, r3
     for name in ('f16', 'bf16'):
         r = rec[name]
         a_, n_ = map(int, r['agree_decidable'].split('/'))
@@ -380,3 +382,74 @@ def test_config5_mcts_s256_bf16_smoke(adm):
     # every simulation pushes at least its rollout's rows (or none at the last step) and at most an expansion + a full rollout
     assert ns * b <= h['net_rows'] <= ns * (2 * b + S * (2 * b + 2 * ns))
     print(f'config 5 smoke: S=256, {ns} sigma steps, bf16: {h["net_rows"]} denoiser rows, final score {float(h["final_scores"][0]):.4f}')
+
+
+# ---- against outputs of THE REFERENCE ITSELF at full size (tests/golden/make_golden_fullsize.py): no oracle in between ----
+@pytest.mark.parametrize('dtype', [torch.float32, X3])
+def test_fullsize_forwards_match_reference_goldens(golden_full, manifest_full, dtype):
+    """ADM ImageNet-64, DDPM++ CIFAR-32 and the ImageNet-64 classifier, 2 rows each, in both parity-grade modes against the reference
+    modules' own outputs on the same weights (checksum-pinned) and inputs."""
+    from helpers import full_weights
+    from diffusion_tts_amd.classifier import EncoderUNetModel
+    from diffusion_tts_amd.networks import EDMPrecond
+    from diffusion_tts_amd.scorers import ImageNetScorer
+    for tag, which, L in (('adm64', 'adm_imagenet64', 1000), ('ddpmpp32', 'ddpmpp_cifar10', 10)):
+        cfg, sd = full_weights(manifest_full, which)
+        x, s, D = (torch.from_numpy(golden_full[f'fwd_{tag}_{k}']) for k in ('x', 'sigma', 'D'))
+        lab = torch.eye(L)[torch.from_numpy(golden_full[f'fwd_{tag}_label_idx']).long()]
+        got = EDMPrecond(cfg, sd, device=DEV, dtype=dtype)(x, s, lab).cpu()
+        err = (got - D).abs().max().item() / max(1.0, D.abs().max().item())
+        print(f'{which} vs the reference, {dtype}: max err / max|D| = {err:.2e}')
+        assert err < 3e-6, (which, str(dtype), err)
+    ccfg, csd = full_weights(manifest_full, 'cls_imagenet64')
+    img = torch.from_numpy(golden_full['cls64_images'])
+    logits = EncoderUNetModel(ccfg, csd, device=DEV, dtype=dtype)((img.float() / 255.0).to(DEV), torch.zeros(2, device=DEV)).cpu()
+    ref = torch.from_numpy(golden_full['cls64_logits'])
+    e = (logits - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    print(f'classifier-64 logits vs the reference, {dtype}: {e:.2e}')
+    assert e < 1e-5, e
+    lab = torch.eye(1000)[torch.from_numpy(golden_full['cls64_label_idx']).long()]
+    sc = ImageNetScorer(weights=csd, cfg=ccfg, device=DEV, compute_dtype=dtype)(img.to(DEV), lab.to(DEV), torch.zeros(2, device=DEV)).cpu()
+    assert np.allclose(sc.numpy(), golden_full['cls64_rewards'], rtol=1e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, X3])
+def test_config3_n64_search_matches_the_reference_run(golden_full, manifest_full, dtype):
+    """BASELINE.json configs[2] at the headline candidate count against THE REFERENCE'S OWN generate_image_grid run (edm/main.py:714-886,
+    full ADM-64 + full classifier, N = 64, K = 1, two sigma steps from sigma_max = 3, seed 0, PYTHONHASHSEED=0): all 64 rewards of both
+    decisions, the selected indices bit-exact (decision 0: reference top-2 gap 3.5e-7; decision 1: sigma 0.002 < S_min, no churn, all 64
+    candidates identical -> an exact tie resolved by the first-max rule), the denoiser row count, the final fp64 state and the uint8 image."""
+    from helpers import full_weights
+    from diffusion_tts_amd import sampler as sm, scorers as S
+    from diffusion_tts_amd.hashing import seed0_scale
+    from diffusion_tts_amd.networks import EDMPrecond
+    m = manifest_full['eg64']
+    cfg, sd = full_weights(manifest_full, 'adm_imagenet64')
+    ccfg, csd = full_weights(manifest_full, 'cls_imagenet64')
+    net = EDMPrecond(cfg, sd, device=DEV, dtype=dtype)
+    scorer = S.ImageNetScorer(weights=csd, cfg=ccfg, device=DEV, compute_dtype=dtype)
+    lat = torch.from_numpy(golden_full['eg64_latents'])
+    lab = torch.eye(1000)[torch.from_numpy(golden_full['eg64_label_idx']).long()]
+    h = sm.generate_image_grid(net, None, lat, lab, seed=m['seed'], gridw=1, gridh=1, device=torch.device(DEV), num_steps=m['num_steps'],
+                               sigma_max=m['sigma_max'], sampling_method=sm.SamplingMethod.EPS_GREEDY,
+                               sampling_params=dict(scorer=scorer, **m['params']), scale_fn=seed0_scale, compute_dtype=dtype, verbose=False, **m['S'])
+    assert h['net_rows'] == m['net_rows'] == 195
+    errs = []
+    for j in (0, 1):
+        got, ref = h['rewards'][j].reshape(-1).numpy(), golden_full[f'eg64_rewards{j}']
+        errs.append(float(np.abs(got - ref).max()))
+        assert int(h['selected'][j][0]) == int(golden_full['eg64_selected'][j]), (j, h['selected'][j], golden_full['eg64_selected'][j])
+    assert np.array_equal(h['rewards'][1].reshape(-1).numpy(), np.full(64, h['rewards'][1].reshape(-1)[0].item(), dtype=np.float32))      # the tie is exact here too
+    # the final state: the last step is an Euler step to sigma = 0, x_next = x_hat - t * (x_hat - D) / t = D of the reference's last call
+    x_err = float((h['x'].cpu() - torch.from_numpy(golden_full['eg64_last_D']).double()).abs().max())
+    x1_err = float((h['x'].cpu() * 0 + torch.from_numpy(golden_full['eg64_last_x']).double() - torch.from_numpy(golden_full['eg64_x_after_step0']).double()).abs().max())
+    assert x1_err == 0.0                                             # (golden self-consistency: no churn noise at sigma 0.002)
+    print(f'config 3, N=64, two steps vs the reference run, {dtype}: reward errs {errs}, reference top-2 gap {m["top2_gaps"][0]:.2e}, '
+          f'final score {float(h["final_scores"][0]):.6e} (reference {float(golden_full["eg64_final_score"][0]):.6e})')
+    assert max(errs) < 5e-8 and m['top2_gaps'][0] > 4 * errs[0]
+    assert abs(float(h['final_scores'][0]) - float(golden_full['eg64_final_score'][0])) < 5e-8
+    img = h['image'][0].permute(1, 2, 0).numpy().astype(np.int32)
+    diff = np.abs(img - golden_full['eg64_image'].astype(np.int32))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.005
+    print(f'  final state vs the reference: max |x - x_ref| = {x_err:.2e}')
+    assert x_err < 1e-3                                              # north_star: final images within 1e-3 abs

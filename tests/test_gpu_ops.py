@@ -97,8 +97,8 @@ def test_conv2d(ops, dtype, case):
 @pytest.mark.parametrize('case', ['3x3', '1x1', 'up', 'cat', 'full_epilogue', 'ragged', 'tile192', 'tile576', 'splitk_full', 'pp192', 'pp128',
                                   'pp_res', 'tiny_values', 'huge_weights'])
 def test_conv2d_split_precision(ops, case):
-    """dtype F16X3: float32 activations, convolution on the 16-bit matrix cores over the f16 split image hi | lo | hi against weights packed
-    hi | hi | lo (dts.h).  Products carry ~22 bits: the result must sit at the f32 parity kernel's distance from the f64 reference (not at
+    """dtype F16X3: float32 activations, convolution on the 16-bit matrix cores over the f16 split image (per 32 channels hi | lo * 2^11) against
+    weights packed per 32 input channels as hi | lo, three MFMAs per staged K step (dts.h).  Products carry ~22 bits: the result must sit at the f32 parity kernel's distance from the f64 reference (not at
     f16's 2^-11), on every launch form: implicit GEMM (4 / 8 waves, split K + reduce), ping-pong with 192- and 128-cout blocks, concat,
     fused upsample, full epilogue (bias, per-sample bias, residual, scale), ragged tiles; operands whose lo parts are f16-subnormal."""
     gen = g(5)
@@ -144,7 +144,7 @@ def test_conv2d_split_precision(ops, case):
     try:
         x1d, x2d = to_nhwc(ops, x1, torch.float32), (None if x2 is None else to_nhwc(ops, x2, torch.float32))
         w3 = ops.pack_conv_weight(wt.to(DEV), ops.F16X3)
-        assert tuple(w3.shape) == (cout, k, k, c1 + c2) and w3.packed.shape[-1] == 3 * (c1 + c2) and w3.packed.dtype == torch.float16
+        assert tuple(w3.shape) == (cout, k, k, c1 + c2) and w3.packed.shape[-1] == 2 * (c1 + c2) and w3.packed.dtype == torch.float16
         if case.startswith('pp'):
             assert ops.conv_kernel(x1d, w3) in (4, 6)
         out = ops.conv2d(x1d, w3, bias.to(DEV), x2=x2d, up=up, gn_stats=True, **kw)
@@ -161,10 +161,37 @@ def test_conv2d_split_precision(ops, case):
         assert torch.allclose(out._gn_stats, out32._gn_stats, rtol=1e-4, atol=1e-4 * max(1.0, scale) ** 2)
 
 
+def test_split_images_saturate_instead_of_poisoning(ops):
+    """an activation beyond the f16 range (|x| >= 65520; |qkv| >= 1024 for the attention image, which carries 2^6) used to become
+    hi = inf, lo = x - inf = NaN in the operand image and from there NaN in every output the element touches.  The images saturate at the
+    largest finite f16 value instead (a clamped operand, not a poisoned search); a NaN stays a NaN; everything in range is untouched."""
+    x = torch.zeros(1, 1, 2, 64)
+    x[0, 0, 0, :6] = torch.tensor([7.0e4, -3.0e5, 65504.0, 1.0e-3, float('inf'), -1.5])
+    x[0, 0, 1, 0] = float('nan')
+    xd = x.to(DEV)
+    img = ops.SplitAct(ops.split3_f16(xd), 64)
+    hi, lo = (t.float().cpu() for t in img.planes())
+    assert torch.equal(hi[0, 0, 0, :3], torch.tensor([65504.0, -65504.0, 65504.0])) and torch.equal(lo[0, 0, 0, :3], torch.zeros(3))
+    assert float(hi[0, 0, 0, 4]) == 65504.0 and float(lo[0, 0, 0, 4]) == 0.0
+    assert abs(float(hi[0, 0, 0, 3] + lo[0, 0, 0, 3] / 2048.0) - 1.0e-3) < 1e-10 and float(hi[0, 0, 0, 5]) == -1.5
+    assert torch.isnan(hi[0, 0, 1, 0]) and torch.isfinite(hi[0, 0, 0]).all() and torch.isfinite(lo[0, 0, 0]).all()
+    wt = torch.randn(64, 64, 1, 1, generator=g(3)) / 8.0
+    out = ops.conv2d(xd, ops.pack_conv_weight(wt.to(DEV), ops.F16X3)).cpu()
+    want = F.conv2d(x[:, :, :1].clamp(-65504.0, 65504.0).permute(0, 3, 1, 2).double(), wt.double())[0, :, 0, 0]
+    assert torch.isfinite(out[0, 0, 0]).all() and float((out[0, 0, 0].double() - want).abs().max()) < 1e-5 * float(want.abs().max())
+    assert torch.isnan(out[0, 0, 1]).all()                          # the NaN pixel stays visible
+    q_ = torch.zeros(1, 2, 192)
+    q_[0, 0, :3] = torch.tensor([2000.0, -1.0e6, 3.0])
+    sp = torch.empty((1, 2, 384), dtype=torch.float16, device=DEV)
+    ops._call('dts_split2_f16', q_.to(DEV).data_ptr(), 192, sp.data_ptr(), 2)
+    sp = sp.float().cpu()
+    assert torch.equal(sp[0, 0, :3], torch.tensor([65504.0, -65504.0, 192.0])) and torch.equal(sp[0, 0, 192:195], torch.zeros(3)) and torch.isfinite(sp).all()
+
+
 @pytest.mark.parametrize('variant', ['plain', 'concat_ss', 'pool', 'wide'])
 def test_group_norm_split_precision_output(ops, variant):
-    """group_norm(..., split_out=True) (dts_gn_apply_x3): the normalised tensor leaves as the f16 split image hi | lo * 2^11 | hi -- bit for
-    bit what dts_split3_f16 makes of the f32 result of the plain pass -- and a split-precision conv reads it directly."""
+    """group_norm(..., split_out=True) (dts_gn_apply_x3): the normalised tensor leaves as the f16 split image (per 32 channels hi | lo * 2^11)
+    -- bit for bit what dts_split3_f16 makes of the f32 result of the plain pass -- and a split-precision conv reads it directly."""
     gen = g(91)
     n, h, w, c1, c2 = 3, 16, 16, 128, 0
     if variant == 'concat_ss':
@@ -182,7 +209,9 @@ def test_group_norm_split_precision_output(ops, variant):
     assert isinstance(sp, ops.SplitAct) and tuple(sp.shape) == tuple(plain.shape) and sp.data.dtype == torch.float16
     ref3 = ops.split3_f16(plain)
     ndiff = int((sp.data != ref3).sum())
-    rec_a = sp.data[..., :C_].float() + sp.data[..., C_:2 * C_].float() / 2048.0
+    hi16, lo16 = sp.planes()
+    assert sp.data.shape[-1] == 2 * C_ and tuple(hi16.shape) == tuple(plain.shape)
+    rec_a = hi16.float() + lo16.float() / 2048.0
     print(f'gn split {variant}: {ndiff} of {ref3.numel()} f16 values differ from split3(plain); max |reconstructed - plain| = {float((rec_a - plain).abs().max()):.3e}')
     if variant in ('plain', 'concat_ss'):                 # the row kernel: the same f32 values, so the same split image bit for bit
         assert ndiff == 0
@@ -190,8 +219,10 @@ def test_group_norm_split_precision_output(ops, variant):
         # values behind the two results agree to a few ulp, not bit for bit
         assert ndiff < 0.05 * ref3.numel() and float((rec_a - plain).abs().max()) <= 4e-6 * float(plain.abs().max())
     # hi + lo * 2^-11 reproduces the f32 value to ~2^-22, and a split-precision conv takes the image as is
-    hi, lo = sp.data[..., :C_].float(), sp.data[..., C_:2 * C_].float()
-    assert torch.equal(sp.data[..., 2 * C_:], sp.data[..., :C_])
+    hi, lo = hi16.float(), lo16.float()
+    # the layout: channel c's hi half at 64 * (c // 32) + c % 32 of the 2C-wide row, its lo half 32 further
+    cc = torch.arange(C_, device=sp.data.device)
+    assert torch.equal(sp.data[..., 64 * (cc // 32) + cc % 32], hi16) and torch.equal(sp.data[..., 64 * (cc // 32) + cc % 32 + 32], lo16)
     assert float((hi + lo / 2048.0 - plain).abs().max()) < 4e-7 * max(1.0, float(plain.abs().max()))
     wt = torch.randn(64, C_, 1, 1, generator=gen) / math.sqrt(C_)
     w3 = ops.pack_conv_weight(wt.to(DEV), ops.F16X3)
@@ -578,7 +609,7 @@ def test_split_precision_attention_block_without_f32_tensors(ops):
     assert torch.equal(fused.data.view(n, hh * ww, 6 * c), sp)
     a32 = ops.attention(plain.view(n, hh * ww, 3 * c), heads, 0.125, x3=True)
     a3 = ops.attention(fused.view(n, hh * ww, 3 * c), heads, 0.125, x3=True, split_out=True)
-    assert isinstance(a3, ops.SplitAct) and torch.equal(a3.data.view(n, hh * ww, 3 * c), ops.split3_f16(a32.view(n, hh * ww, 1, c)).view(n, hh * ww, 3 * c))
+    assert isinstance(a3, ops.SplitAct) and torch.equal(a3.data.view(n, hh * ww, 2 * c), ops.split3_f16(a32.view(n, hh * ww, 1, c)).view(n, hh * ww, 2 * c))
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])

@@ -107,6 +107,40 @@ def run_case(pkg, golden, manifest, case, dtype, **extra):
     return meta, res
 
 
+def test_defaults_are_the_parity_grade_mode(pkg, golden, manifest):
+    """What a maintainer gets WITHOUT passing any dtype keyword: EDMPrecond, ImageNetScorer and
+    generate_image_grid default to the split-precision mode, and a default-constructed search reproduces the reference's rewards
+    (atol 5e-5), selected indices and uint8 image -- north_star: "results match the reference on the same seed"."""
+    import inspect
+    from diffusion_tts_amd import ops
+    sm, S, N = pkg['sampler'], pkg['scorers'], pkg['networks']
+    assert inspect.signature(sm.generate_image_grid).parameters['compute_dtype'].default == ops.F16X3
+    assert inspect.signature(N.EDMPrecond.__init__).parameters['dtype'].default == ops.F16X3
+    assert inspect.signature(S.ImageNetScorer.__init__).parameters['compute_dtype'].default == ops.F16X3
+    assert inspect.signature(sm.load_network).parameters['dtype'].default == ops.F16X3
+    case = 'epsgreedy_adm_imagenet'
+    meta = manifest['cases'][case]
+    cfg, sd = tiny_edm(manifest, meta['net'])
+    net = N.EDMPrecond(cfg, sd, device=DEV)                                        # no dtype
+    ccfg, csd = tiny_cls(manifest)
+    scorer = S.ImageNetScorer(weights=csd, cfg=ccfg, device=DEV)                   # no compute_dtype
+    assert net.dtype == ops.F16X3 and scorer.model.dtype == ops.F16X3
+    lat, lab = T(golden['search_latents1']), T(golden['search_lab1'])
+    res = sm.generate_image_grid(net, None, lat, lab, seed=meta['seed'], gridw=1, gridh=1, device=torch.device(DEV),
+                                 num_steps=meta['num_steps'], S_churn=40, S_min=0.05, S_max=50, S_noise=1.003,
+                                 sampling_method=sm.SamplingMethod.EPS_GREEDY, sampling_params=dict(scorer=scorer, **meta['params']),
+                                 scale_fn=seed0_scale, verbose=False)                # no compute_dtype
+    assert res['net_rows'] == meta['net_rows']                                     # the reference's row count (final pivot step recomputed)
+    n_ = meta['params']['N']
+    for j, sel in enumerate(res['selected']):
+        ref = golden[f'{case}_score{j}'].reshape(n_, 1)
+        assert np.allclose(res['rewards'][j].numpy().reshape(n_, 1), ref, atol=5e-5)
+        assert np.array_equal(sel.numpy(), ref.argmax(axis=0))
+    img = res['image'][0].permute(1, 2, 0).numpy().astype(np.int32)
+    diff = np.abs(img - golden[f'{case}_image'].astype(np.int32))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.005
+
+
 CASES = ['naive_adm', 'naive_ddpmpp', 'rejection_adm', 'rejection_ddpmpp', 'epsgreedy_adm_bright',
          'epsgreedy_adm_imagenet', 'zeroorder_adm', 'mcts_adm']
 

@@ -111,3 +111,67 @@ def test_flop_counters_match_reference_measurement(manifest):
     assert abs(adm['total'] - manifest['adm_imagenet64']['flops']) / manifest['adm_imagenet64']['flops'] < 2e-3
     assert abs(song['total'] - manifest['ddpmpp_cifar10']['flops']) / manifest['ddpmpp_cifar10']['flops'] < 2e-3
     assert abs(cls['total'] - manifest['cls_imagenet64']['flops']) / manifest['cls_imagenet64']['flops'] < 2e-3
+
+
+# ---- the oracle pinned AT FULL SIZE by outputs of the reference itself (tests/golden/make_golden_fullsize.py) -------
+def test_fullsize_denoisers_match_reference(golden_full, manifest_full):
+    """The 192-wide, 3-blocks-per-level, heads 6/9/12 ADM ImageNet-64 (networks.py:372-461) and the 128-wide DDPM++ CIFAR-32
+    (networks.py:229-363): the oracle's 2-row forward against the REFERENCE module's on the same weights and inputs."""
+    from helpers import full_weights
+    torch.set_num_threads(8)
+    for tag, which, L in (('adm64', 'adm_imagenet64', 1000), ('ddpmpp32', 'ddpmpp_cifar10', 10)):
+        cfg, sd = full_weights(manifest_full, which)
+        x, s, D = (T(golden_full[f'fwd_{tag}_{k}']) for k in ('x', 'sigma', 'D'))
+        lab = torch.eye(L)[T(golden_full[f'fwd_{tag}_label_idx']).long()]
+        got = oracle_net(cfg, sd)(x, s, lab)
+        err = (got - D).abs().max().item() / max(1.0, D.abs().max().item())
+        print(f'oracle vs reference, {which}: max err / max|D| = {err:.2e}')
+        assert got.dtype == torch.float32 and err < 2e-5, (which, err)
+
+
+def test_fullsize_classifier_and_scorer_match_reference(golden_full, manifest_full):
+    """The w = 128, d = 4 ImageNet-64 classifier (unet.py:701-912) and ImageNetScorer.__call__ (scorers.py:143-174) at full size."""
+    from helpers import full_weights
+    torch.set_num_threads(8)
+    cfg, sd = full_weights(manifest_full, 'cls_imagenet64')
+    img = T(golden_full['cls64_images'])
+    ocfg = oracle_cls_cfg(cfg)
+    logits = encoder_unet(sd, ocfg, img.float() / 255.0, torch.zeros(2))
+    ref = golden_full['cls64_logits']
+    assert np.abs(logits.numpy() - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+    lab = torch.eye(1000)[T(golden_full['cls64_label_idx']).long()]
+    sc = oscore.ImageNetOracle(ocfg, sd)(img, lab, torch.zeros(2))
+    assert np.allclose(sc.numpy(), golden_full['cls64_rewards'], rtol=1e-4, atol=1e-9)
+
+
+class _StopAfterFirstDecision(Exception):
+    pass
+
+
+def test_fullsize_eps_greedy_n64_first_decision_matches_reference(golden_full, manifest_full):
+    """ONE N = 64 eps-greedy iteration with the full ADM-64 denoiser and the full classifier: the oracle's 64 rewards and its argmax
+    against what the reference's own generate_image_grid computed (edm/main.py:749-842) from the same latents, seed and hash table.
+    (The oracle is stopped after the first scorer call: 128 denoiser rows + 64 classifier images, ~1.5 min on 8 cores; the GPU suite
+    runs the whole 2-step search against the same golden.)"""
+    from helpers import full_weights
+    torch.set_num_threads(8)
+    m = manifest_full['eg64']
+    cfg, sd = full_weights(manifest_full, 'adm_imagenet64')
+    ccfg, csd = full_weights(manifest_full, 'cls_imagenet64')
+    inner = oscore.ImageNetOracle(oracle_cls_cfg(ccfg), csd)
+    seen = []
+
+    def scorer(images, labels, ts):
+        seen.append(inner(images, labels, ts))
+        raise _StopAfterFirstDecision
+
+    lat = T(golden_full['eg64_latents'])
+    lab = torch.eye(1000)[T(golden_full['eg64_label_idx']).long()]
+    with pytest.raises(_StopAfterFirstDecision):
+        osamp.search(oracle_net(cfg, sd), lat, lab, method='eps_greedy', params=dict(scorer=scorer, **m['params']), seed=m['seed'],
+                     num_steps=m['num_steps'], sigma_max=m['sigma_max'], scale_fn=seed0_scale, **m['S'])
+    got, ref = seen[0].numpy(), golden_full['eg64_rewards0']
+    err = np.abs(got - ref).max()
+    print(f'oracle vs reference, config-3 N=64 decision 0: max reward err {err:.2e}, reference top-2 gap {m["top2_gaps"][0]:.2e}, argmax {int(got.argmax())}')
+    assert err < 5e-8 and m['top2_gaps'][0] > 4 * err
+    assert int(got.argmax()) == int(golden_full['eg64_selected'][0]) == m['selected'][0]
