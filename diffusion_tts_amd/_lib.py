@@ -101,7 +101,7 @@ def check(status, what=''):
         raise RuntimeError(f'libdts_hip {what} failed ({status}): {msg}')
 
 
-KNOBS = {'att_xcd': 0, 'att_qt': 1, 'conv_tile': 2, 'conv_splits': 3, 'conv_variant': 4, 'gn_fuse': 5, 'att_db': 6, 'conv_stages': 7, 'conv_waves': 8, 'conv_half_round': 9}
+KNOBS = {'att_xcd': 0, 'att_qt': 1, 'conv_tile': 2, 'conv_splits': 3, 'conv_variant': 4, 'gn_fuse': 5, 'att_db': 6, 'conv_stages': 7, 'conv_waves': 8, 'conv_half_round': 9, 'conv_epi32': 10}
 
 
 def set_tuning(name, value):

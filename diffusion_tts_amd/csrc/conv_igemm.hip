@@ -60,6 +60,7 @@ struct ConvP {
   int w_shift, hw_shift;   // log2(wout), log2(hout*wout) when both are powers of two, else -1 (pixel coordinates by division)
   const float* gn_coef;    // optional [n][cin][2] (a, b): GroupNorm of the INPUT applied on the staged halo tile (conv_pp_kernel only)
   int gn_silu;
+  int epi_rows;            // f32 outputs: 1 = the row-layout epilogue (conv_epilogue_rows_f32), 0 = the accumulator-layout one (DTS_CONV_EPI32=0)
 };
 
 template <typename T> struct Mma;
@@ -402,6 +403,113 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvP& kp, f32x4_t (&ac
   }
 }
 
+// ---- epilogue for f32 outputs (the f32 parity mode and the split-precision mode), whole pixel tiles: WAVE-PRIVATE transpose through LDS.
+// The accumulator layout gives a lane 4 couts of one pixel: a store instruction of the accumulator-layout epilogue below covers 16 pixel
+// rows x 64 bytes, its residual loads likewise (three dependent round trips: 96 residual registers do not fit beside 96 accumulators), and
+// its strip statistics cost 32 ds_bpermute per 16-cout slice.  In-kernel stamps (tools/conv_stamps.py --dtype f16x3, round 5): 19.7k cycles
+// per ping-pong block without a residual, 33k..45k with one (20 % of a 64x64 192 -> 192 block), and 20k..29k of a 1x1 block whose whole K
+// loop is 32k..49k.  Here each wave transposes ITS OWN 16*MT couts x 64 pixels through its private LDS slice in two halves of 32 pixels --
+// no block barrier: a wave's LDS operations execute in order -- and works in ROW layout: a lane holds 4 consecutive couts (fixed for the
+// lane: bias and per-sample bias live in registers) of RPI pixels per trip, residual loads and output stores are 16 bytes per lane over
+// whole 64*MT-byte row segments, all residual loads of a half are in flight before its first use, and the strip moments are summed per
+// lane (one cross-lane step at the end).  Arithmetic and order per element are the accumulator-layout path's: outputs are bit-identical;
+// the strip moments are summed in another (fixed) order, so EVERY tile of a launch must take the same path -- identical candidate rows
+// must give identical outputs wherever they sit in the batch (tests: rows independent of batch position): the path is chosen by the
+// layer shape (hout * wout a multiple of 64: strips never straddle samples or the end of the batch), never by the tile's position.
+// What it does NOT buy (measured, round 5): with one block per CU the blocks of a launch reach their epilogues together, and 196 KB of f32
+// output (+ 196 KB of residual) per block at a 256th of the HBM rate is ~20k (+ 20k) cycles whatever the instruction stream does: -13 % on
+// the 1x1 layers, -3 % on the ping-pong residual layers, +1.8 % on the N = 64 step (profiles/r05_experiments.txt).
+template <int MT, int NT>
+__device__ __forceinline__ void conv_epilogue_rows_f32(const ConvP& kp, f32x4_t (&acc)[MT][NT], int cm0, const TileMap& tm, int wm, int wn,
+                                                       int lrow, int lq, char* smem, int wave) {
+  static_assert(NT == 4, "64-pixel wave strips");
+  constexpr int CW = 16 * MT;                          // couts of this wave's rows
+  constexpr int LPR = 4 * MT;                          // lanes per row (one float4 each)
+  constexpr int RPI = LPR <= 8 ? 8 : (LPR <= 16 ? 4 : 2);      // rows per trip (a power of two: divides the 32 rows of a half)
+  constexpr int ITERS = 32 / RPI;
+  constexpr int ROWB = CW * 4 + 16;                    // LDS row pitch: +4 dwords, so the 8 rows of a ds_write_b128 lane group start 4-bank groups apart
+  char* const ws = smem + (size_t)wave * (32 * ROWB);
+  const int lane = threadIdx.x & 63;
+  const int rsub = lane / LPR, c4 = lane - rsub * LPR;
+  const bool act = rsub < RPI;
+  const int p_cout = kp.cout;
+  const int co = cm0 + wm * CW + c4 * 4;
+  const float* __restrict__ res = reinterpret_cast<const float*>(kp.residual);
+  if (tm.pix(wn * 64) >= kp.P) return;                 // this wave's strip lies beyond the batch (ragged last tile): whole strips only, see above
+  float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), n4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (act) {
+    if (kp.bias) b4 = *reinterpret_cast<const float4*>(kp.bias + co);
+    if (kp.bias_nc) {                                  // a 64-pixel strip lies inside one sample
+      const int pp0 = tm.pix(wn * 64), hw = kp.hout * kp.wout;
+      n4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(kp.bias_nc) + (size_t)(kp.hw_shift >= 0 ? pp0 >> kp.hw_shift : pp0 / hw) * kp.ld_bias_nc + co);
+    }
+  }
+  const float asc = kp.acc_scale, osc = kp.out_scale;
+  const bool want_stats = kp.stats != nullptr;
+  float ss4[4] = {0.f, 0.f, 0.f, 0.f}, sq4[4] = {0.f, 0.f, 0.f, 0.f};
+  typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+  constexpr int CH = ITERS < 8 ? ITERS : 8;            // trips per residual batch (all CH loads in flight; 16 at once spilled the 96-cout forms)
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        *reinterpret_cast<f32x4_t*>(ws + (n2 * 16 + lrow) * ROWB + (mt * 16 + lq * 4) * 4) = acc[mt][half * 2 + n2];
+#pragma unroll
+   for (int u0 = 0; u0 < ITERS; u0 += CH) {
+    size_t prow[CH];                                   // element offset of this lane's pixel row of each trip (x cout)
+    float4 rv[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      prow[u] = (size_t)tm.pix(wn * 64 + half * 32 + (u0 + u) * RPI + (act ? rsub : 0)) * p_cout + co;
+      rv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (res && act) rv[u] = *reinterpret_cast<const float4*>(res + prow[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      if (!act) continue;
+      const f32x4_t a = *reinterpret_cast<const f32x4_t*>(ws + ((u0 + u) * RPI + rsub) * ROWB + c4 * 16);
+      float v[4] = {a[0] * asc + b4.x, a[1] * asc + b4.y, a[2] * asc + b4.z, a[3] * asc + b4.w};      // (acc_scale is 1 outside the split-precision mode)
+      if (kp.bias_nc) { v[0] += n4.x; v[1] += n4.y; v[2] += n4.z; v[3] += n4.w; }
+      if (res) { v[0] += rv[u].x; v[1] += rv[u].y; v[2] += rv[u].z; v[3] += rv[u].w; }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= osc;
+      if (kp.out_split2) {                             // the qkv projection of the split-precision mode: the attention's operand image
+        float hi[4], lo[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x2_split(v[r], hi[r], lo[r]);
+        f16_t* orow = reinterpret_cast<f16_t*>(kp.out) + 2 * (prow[u] - co) + co;
+        *reinterpret_cast<uint2*>(orow) = make_uint2(pack2_f16(hi[0], hi[1]), pack2_f16(hi[2], hi[3]));
+        *reinterpret_cast<uint2*>(orow + p_cout) = make_uint2(pack2_f16(lo[0], lo[1]), pack2_f16(lo[2], lo[3]));
+      } else {
+        const f32x4_nt o = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(o, reinterpret_cast<f32x4_nt*>(reinterpret_cast<float*>(kp.out) + prow[u]));
+      }
+      if (want_stats) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ss4[r] += v[r]; sq4[r] += v[r] * v[r]; }
+      }
+    }
+   }
+  }
+  if (want_stats) {
+    // the RPI lanes that hold the same couts (lane = rsub * LPR + c4) are summed in a fixed order: deterministic, no atomics
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float s_ = ss4[r], q_ = sq4[r];
+#pragma unroll
+      for (int k = 1; k < RPI; ++k) { s_ += __shfl(ss4[r], c4 + k * LPR, 64); q_ += __shfl(sq4[r], c4 + k * LPR, 64); }
+      ss4[r] = s_; sq4[r] = q_;
+    }
+    if (rsub == 0) {
+      float4* d = reinterpret_cast<float4*>(kp.stats + ((size_t)tm.strip(wn) * p_cout + co) * 2);
+      d[0] = make_float4(ss4[0], sq4[0], ss4[1], sq4[1]);
+      d[1] = make_float4(ss4[2], sq4[2], ss4[3], sq4[3]);
+    }
+  }
+}
+
 // ---- epilogue of one (cout tile, pixel tile[, K split]): lane holds couts co..co+3 of pixel pp for each (mt, nt)
 // RING: bytes of the caller's (idle) LDS ring, which the staged output tile reuses
 template <typename T, int MT, int NT, int BM, int BN, int NTHR, int RING>
@@ -423,6 +531,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& kp, f32x4_t (&acc)[MT
       }
     }
     return;
+  }
+  if constexpr (sizeof(T) == 4 && NT == 4) {
+    constexpr int NWV = NTHR / 64;
+    static_assert(NWV * 32 * (16 * MT * 4 + 16) <= RING, "the waves' private transpose slices must fit the caller's LDS ring");
+    if (kp.epi_rows && (p_hout * p_wout) % 64 == 0) {  // launch-uniform (by layer shape, not by tile position: see conv_epilogue_rows_f32)
+      conv_epilogue_rows_f32<MT, NT>(kp, acc, cm0, tm, wm, wn, lrow, lq, smem, (int)(threadIdx.x >> 6));
+      return;
+    }
   }
   if constexpr (sizeof(T) == 2) {
     if (tm.pn0 + BN <= p_P) {                          // block-uniform
@@ -1470,11 +1586,12 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, C
     while (smax > 1 && (long long)smax * p.P * p.cout * 4 > ws_bytes) --smax;
     if (smax < 1) smax = 1;
     const bool can8 = sizeof(T) == 2 && MT % 2 == 0;
+    constexpr double KS = std::is_same<T, OT>::value ? 1.0 : 1.5;        // a split-precision K step carries 3 MFMAs per tile instead of 2
     auto est = [&](int s_) {
       const int steps = (nk + s_ - 1) / s_;
       double t;
-      if (can8 && (long long)nblk * s_ <= 256) t = 5.0 + steps * 0.75;
-      else t = (double)((nblk * s_ + slots - 1) / slots) * (5.5 + steps * 1.25);
+      if (can8 && (long long)nblk * s_ <= 256) t = 5.0 + steps * 0.75 * KS;
+      else t = (double)((nblk * s_ + slots - 1) / slots) * (5.5 + steps * 1.25 * KS);
       if (s_ > 1) t += 3.0 + (s_ + 0.5) * (double)p.P * p.cout * 4.0 / 4.0e6;
       return t;
     };
@@ -1564,7 +1681,7 @@ int launch_conv_pp(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes
         for (int s_ = 1; s_ <= 8 && s_ <= nchunk; ++s_) {
           const int cps = (nchunk + s_ - 1) / s_, se = (nchunk + cps - 1) / cps;
           if (se != s_ || nblk * se > 256) continue;
-          double t = 5.0 + cps * TAPS * 1.05;
+          double t = 5.0 + cps * TAPS * (std::is_same<T, OT>::value ? 1.05 : 1.4);      // (split precision: 72 MFMAs per tile and wave instead of 48)
           if (se > 1) t += 3.0 + (se + 0.5) * (double)p.P * p.cout * 4.0 / 4.0e6;
           if (t < best) { best = t; splits = se; }
         }
@@ -1785,6 +1902,11 @@ extern "C" int dts_conv2d(dts_conv_args* a, dts_stream s) {
     if ((p.wout & (p.wout - 1)) == 0 && (hw & (hw - 1)) == 0) { p.w_shift = __builtin_ctz(p.wout); p.hw_shift = __builtin_ctz(hw); }
   }
   p.gn_coef = a->gn_coef; p.gn_silu = a->gn_silu;
+  {   // the row-layout f32 epilogue: the split-precision mode's default; the f32 parity mode keeps the accumulator-layout epilogue (the mode is the
+      // REFERENCE the others are compared with: its summation orders stay what rounds 2-4 validated against the CPU oracle) unless DTS_CONV_EPI32=1
+    const int k_ = dts_knob_get(DTS_KNOB_CONV_EPI32);
+    p.epi_rows = k_ < 0 ? (a->dtype == DTS_F16X3 ? 1 : 0) : (k_ != 0);
+  }
   DTS_CHECK_ARG(a->gn_coef == nullptr || dts_conv_fuses_gn(a), "dts_conv2d: gn_coef given for a launch that cannot fuse the GroupNorm apply "
                 "(ask dts_conv_fuses_gn first)");
   p.stats = a->stats_out;

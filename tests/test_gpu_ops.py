@@ -173,7 +173,7 @@ def test_split_images_saturate_instead_of_poisoning(ops):
     hi, lo = (t.float().cpu() for t in img.planes())
     assert torch.equal(hi[0, 0, 0, :3], torch.tensor([65504.0, -65504.0, 65504.0])) and torch.equal(lo[0, 0, 0, :3], torch.zeros(3))
     assert float(hi[0, 0, 0, 4]) == 65504.0 and float(lo[0, 0, 0, 4]) == 0.0
-    assert abs(float(hi[0, 0, 0, 3] + lo[0, 0, 0, 3] / 2048.0) - 1.0e-3) < 1e-10 and float(hi[0, 0, 0, 5]) == -1.5
+    assert abs(float(hi[0, 0, 0, 3].double() + lo[0, 0, 0, 3].double() / 2048.0) - float(x[0, 0, 0, 3])) < 4e-10 and float(hi[0, 0, 0, 5]) == -1.5
     assert torch.isnan(hi[0, 0, 1, 0]) and torch.isfinite(hi[0, 0, 0]).all() and torch.isfinite(lo[0, 0, 0]).all()
     wt = torch.randn(64, 64, 1, 1, generator=g(3)) / 8.0
     out = ops.conv2d(xd, ops.pack_conv_weight(wt.to(DEV), ops.F16X3)).cpu()

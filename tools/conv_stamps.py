@@ -30,6 +30,9 @@ def main():
     ap.add_argument('--stages', type=int, default=-1)
     ap.add_argument('--splits', type=int, default=-1)
     ap.add_argument('--build-only', action='store_true')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f16x3'])
+    ap.add_argument('--res', action='store_true', help='with a residual input')
+    ap.add_argument('--only', default='', help='substring filter on the shape names')
     a = ap.parse_args()
     if not os.path.exists(LIB) or a.build_only:
         build()
@@ -46,20 +49,30 @@ def main():
     for k_, v_ in (('conv_variant', a.variant), ('conv_stages', a.stages), ('conv_splits', a.splits)):
         if v_ >= 0:
             _lib.set_tuning(k_, v_)
-    dt = torch.bfloat16
+    x3 = a.dtype == 'f16x3'
+    dt = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f16x3': torch.float32}[a.dtype]
     for name, r, cin, cout, k in SHAPES:
+        if a.only not in name:
+            continue
         x = torch.randn(a.n, r, r, cin, device='cuda').to(dt)
-        w = (torch.randn(cout, k, k, cin, device='cuda') / (cin * k * k) ** 0.5).to(dt)
+        if x3:      # the conv reads a split image (as inside the network, where the GroupNorm apply wrote it): no split pass in the timing
+            w = ops.pack_conv_weight((torch.randn(cout, cin, k, k, device='cuda') / (cin * k * k) ** 0.5), ops.F16X3)
+            x = ops.SplitAct(ops.split3_f16(x), cin)
+        else:
+            w = (torch.randn(cout, k, k, cin, device='cuda') / (cin * k * k) ** 0.5).to(dt)
         b = torch.randn(cout, device='cuda')
         out = torch.empty(a.n, r, r, cout, device='cuda', dtype=dt)
+        res_ = torch.randn(a.n, r, r, cout, device='cuda').to(dt) if a.res else None
+        _conv = ops.conv2d
+        ops_conv2d = lambda *aa, **kk: _conv(*aa, residual=res_, **kk)
         for _ in range(3):
-            ops.conv2d(x, w, b, out=out, gn_stats=True)
+            ops_conv2d(x, w, b, out=out, gn_stats=True)
         torch.cuda.synchronize()
         assert lib.dts_debug_clear_stamps() == 0
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda._sleep(200_000)
         e0.record()
-        ops.conv2d(x, w, b, out=out, gn_stats=True)
+        ops_conv2d(x, w, b, out=out, gn_stats=True)
         e1.record()
         torch.cuda.synchronize()
         buf = np.zeros(8192 * 8, dtype=np.uint64)
@@ -84,7 +97,7 @@ def main():
             assert lib.dts_debug_read_segments(sb.ctypes.data, sb.size) == 0
             sg = sb.reshape(4096, 2, 8).astype(np.int64)
             ok = sg[:, 0, 3] != 0
-            tiles = k * k * (cin // 64) / max(1, round(int(ok.sum()) / ((a.n * r * r // 256) * (cout // (32 * kern)))))
+            tiles = k * k * ((2 * cin if x3 else cin) // 64) / max(1, round(int(ok.sum()) / ((a.n * r * r // 256) * (cout // (32 * kern)))))
             names = ['DMA issue', 'frag reads', 'LOAD barrier', 'MFMA', 'vmcnt', 'COMPUTE barrier']
             for g_ in (0, 1):
                 med = np.median(sg[ok][:, g_, :6], axis=0) / tiles
