@@ -37,7 +37,7 @@ SIGNATURES = {
     'dts_gn_coef': [_p, _i, _p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _i, _p, _p, _p],
     'dts_gn_coef_strips': [_p, _i, _p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _i, _p, _p],
     'dts_gn_apply': [_p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _i, _p],
-    'dts_gn_apply_x3': [_p, _i, _p, _i, _p, _p, _i, _i, _i, _i, _i, _p],
+    'dts_gn_apply_x3': [_p, _i, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     'dts_gn_fused': [_p, _i, _p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _i, _p, _i, _p],
     'dts_resample2x': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
     'dts_attention': [_p, _p, _i, _i, _i, _i, _i, _f, _p],

@@ -86,8 +86,13 @@ class EncoderUNetModel:
 
     def _res(self, L: ClsLayer, x, emb_all):
         P = self.params[L.prefix]
-        h = ops.group_norm(x, 32, 1e-5, P.g0, P.b0, silu=True, pool=L.down, split_out=self.x3)
-        if L.down:
+        # (split-precision mode, blocks with a 1x1 skip convolution: the norm pass also writes the skip convolution's operand image of the raw
+        # [2x2-averaged] input: networks.EDMPrecond._block)
+        raw = self.x3 and P.sw is not None
+        h = ops.group_norm(x, 32, 1e-5, P.g0, P.b0, silu=True, pool=L.down, split_out=self.x3, raw_split=raw)
+        if raw:
+            h, x = h
+        elif L.down:
             x = ops.resample2x(x, up=False)
         h = ops.conv2d(h, P.w0, P.cb0, gn_stats=True)
         ss = emb_all[:, P.off:P.off + 2 * L.cout]

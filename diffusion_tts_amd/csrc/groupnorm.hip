@@ -189,7 +189,9 @@ __device__ __forceinline__ void store_split4(f16_t* orow, int c0, const float* f
 template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const T* __restrict__ x1, int c1, const T* __restrict__ x2, int c2,
                                                              const float* __restrict__ coef, T* __restrict__ out, int hw, int ppb,
-                                                             int silu) {
+                                                             int silu, f16_t* __restrict__ raw = nullptr) {
+  // raw (SPLIT only, optional): the split image of the UN-normalised input rows is written too -- the operand of the block's 1x1 skip
+  // convolution (networks.py:177 `self.skip(orig)`), which would otherwise cost a dts_split3_f16 pass over the same tensor
   static_assert(!SPLIT || sizeof(T) == 4, "split-precision output is the f32 mode's");
   constexpr int EPV = ET<T>::EPV;
   const int C = c1 + c2, nchunk = C / EPV;
@@ -206,6 +208,7 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const T* __restrict_
   if (c0 < c1) { src = x1 + (size_t)n * hw * c1 + c0; cs = c1; } else { src = x2 + (size_t)n * hw * c2 + (c0 - c1); cs = c2; }
   T* dst = out + (size_t)n * hw * C + c0;
   f16_t* const dst3 = reinterpret_cast<f16_t*>(out) + (size_t)n * hw * 2 * C;       // SPLIT: rows of 2C f16
+  f16_t* const raw3 = raw ? raw + (size_t)n * hw * 2 * C : nullptr;
   const int p_begin = blockIdx.x * ppb, p_end = min(hw, p_begin + ppb);
   int p = p_begin + pr;
   // two independent pixels per trip keep two loads in flight per thread
@@ -215,6 +218,9 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const T* __restrict_
     float f0[EPV], f1[EPV];
     unpack16<T>(v0, f0);
     unpack16<T>(v1, f1);
+    if constexpr (SPLIT) {
+      if (raw3) { store_split4(raw3 + (size_t)p * 2 * C, c0, f0); store_split4(raw3 + (size_t)(p + k) * 2 * C, c0, f1); }
+    }
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
       const float y0 = f0[e] * A[e] + B[e], y1 = f1[e] * A[e] + B[e];
@@ -233,6 +239,9 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const T* __restrict_
     const uint4 v0 = *reinterpret_cast<const uint4*>(src + (size_t)p * cs);
     float f0[EPV];
     unpack16<T>(v0, f0);
+    if constexpr (SPLIT) {
+      if (raw3) store_split4(raw3 + (size_t)p * 2 * C, c0, f0);
+    }
 #pragma unroll
     for (int e = 0; e < EPV; ++e) { const float y0 = f0[e] * A[e] + B[e]; f0[e] = silu ? silu_t<T>(y0) : y0; }
     if constexpr (SPLIT) store_split4(dst3 + (size_t)p * 2 * C, c0, f0);
@@ -243,7 +252,8 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const T* __restrict_
 template <typename T, bool POOL, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1, int c1, const T* __restrict__ x2, int c2,
                                                         const float* __restrict__ coef, T* __restrict__ out,
-                                                        int n_total, int h, int w, int silu) {
+                                                        int n_total, int h, int w, int silu, f16_t* __restrict__ raw = nullptr) {
+  // raw (SPLIT only, optional): the split image of the un-normalised [2x2-averaged, with resample_kernel's arithmetic] input rows too
   constexpr int EPV = ET<T>::EPV;
   const int C = c1 + c2, nchunk = C / EPV;
   const int ho = POOL ? h / 2 : h, wo = POOL ? w / 2 : w;
@@ -263,16 +273,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1,
       const float4 q = *reinterpret_cast<const float4*>(coef + ((size_t)n * C + c0 + e) * 2);
       A[e] = q.x; B[e] = q.y; A[e + 1] = q.z; B[e + 1] = q.w;
     }
-    float r[EPV];
+    float r[EPV], rr[EPV];
     if (!POOL) {
       const uint4 v = *reinterpret_cast<const uint4*>(base + (((size_t)n * h + yo) * w + xo) * cs + co);
       float f[EPV];
       unpack16<T>(v, f);
 #pragma unroll
-      for (int e = 0; e < EPV; ++e) { const float y = f[e] * A[e] + B[e]; r[e] = silu ? silu_t<T>(y) : y; }
+      for (int e = 0; e < EPV; ++e) { rr[e] = f[e]; const float y = f[e] * A[e] + B[e]; r[e] = silu ? silu_t<T>(y) : y; }
     } else {
 #pragma unroll
-      for (int e = 0; e < EPV; ++e) r[e] = 0.f;
+      for (int e = 0; e < EPV; ++e) { r[e] = 0.f; rr[e] = 0.f; }
 #pragma unroll
       for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -281,11 +291,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1,
           float f[EPV];
           unpack16<T>(v, f);
 #pragma unroll
-          for (int e = 0; e < EPV; ++e) { const float y = f[e] * A[e] + B[e]; r[e] += 0.25f * (silu ? silu_t<T>(y) : y); }
+          for (int e = 0; e < EPV; ++e) { rr[e] += 0.25f * f[e]; const float y = f[e] * A[e] + B[e]; r[e] += 0.25f * (silu ? silu_t<T>(y) : y); }
         }
     }
-    if constexpr (SPLIT) store_split4(reinterpret_cast<f16_t*>(out) + (((size_t)n * ho + yo) * wo + xo) * 2 * C, c0, r);
-    else *reinterpret_cast<uint4*>(out + (((size_t)n * ho + yo) * wo + xo) * C + c0) = pack16<T>(r);
+    if constexpr (SPLIT) {
+      store_split4(reinterpret_cast<f16_t*>(out) + (((size_t)n * ho + yo) * wo + xo) * 2 * C, c0, r);
+      if (raw) store_split4(raw + (((size_t)n * ho + yo) * wo + xo) * 2 * C, c0, rr);
+    } else
+      *reinterpret_cast<uint4*>(out + (((size_t)n * ho + yo) * wo + xo) * C + c0) = pack16<T>(r);
   }
 }
 
@@ -470,17 +483,18 @@ extern "C" int dts_gn_coef_strips(const float* st1, int c1, const float* st2, in
 }
 
 static int gn_apply_impl(const void* x1, int c1, const void* x2, int c2, int dtype, const float* coef, void* out, int n, int h,
-                         int w, int silu, int pool, bool split, dts_stream s);
+                         int w, int silu, int pool, bool split, dts_stream s, void* raw_out = nullptr);
 extern "C" int dts_gn_apply(const void* x1, int c1, const void* x2, int c2, int dtype, const float* coef, void* out, int n, int h,
                             int w, int silu, int pool, dts_stream s) {
   return gn_apply_impl(x1, c1, x2, c2, dtype, coef, out, n, h, w, silu, pool, false, s);
 }
-extern "C" int dts_gn_apply_x3(const float* x1, int c1, const float* x2, int c2, const float* coef, void* out, int n, int h,
+extern "C" int dts_gn_apply_x3(const float* x1, int c1, const float* x2, int c2, const float* coef, void* out, void* raw_out, int n, int h,
                                int w, int silu, int pool, dts_stream s) {
-  return gn_apply_impl(x1, c1, x2, c2, DTS_F32, coef, out, n, h, w, silu, pool, true, s);
+  DTS_CHECK_ARG((c1 + c2) % 32 == 0, "dts_gn_apply_x3: %d channels are not a multiple of 32", c1 + c2);
+  return gn_apply_impl(x1, c1, x2, c2, DTS_F32, coef, out, n, h, w, silu, pool, true, s, raw_out);
 }
 static int gn_apply_impl(const void* x1, int c1, const void* x2, int c2, int dtype, const float* coef, void* out, int n, int h,
-                         int w, int silu, int pool, bool split, dts_stream s) {
+                         int w, int silu, int pool, bool split, dts_stream s, void* raw_out) {
   const int C = c1 + c2;
   DTS_CHECK_ARG(x1 && coef && out, "dts_gn_apply: null pointer");
   DTS_CHECK_ARG(c2 == 0 || x2, "dts_gn_apply: c2 without x2");
@@ -493,16 +507,16 @@ static int gn_apply_impl(const void* x1, int c1, const void* x2, int c2, int dty
     using T = float;
     if (pool)
       hipLaunchKernelGGL((gn_apply_kernel<T, true, true>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x1, c1, (const T*)x2,
-                         c2, coef, (T*)out, n, h, w, silu);
+                         c2, coef, (T*)out, n, h, w, silu, (f16_t*)raw_out);
     else if (C / epv <= 256 && n <= 65535) {
       const int nchunk = C / epv, k = 256 / nchunk, hw = h * w;
       long long ppb = ((long long)n * hw + 4095) / 4096;
       ppb = ((ppb + 2 * k - 1) / (2 * k)) * (2 * k);
       hipLaunchKernelGGL((gn_apply_rows_kernel<T, true>), dim3((unsigned)((hw + ppb - 1) / ppb), n), dim3(k * nchunk), 0, st, (const T*)x1, c1,
-                         (const T*)x2, c2, coef, (T*)out, hw, (int)ppb, silu);
+                         (const T*)x2, c2, coef, (T*)out, hw, (int)ppb, silu, (f16_t*)raw_out);
     } else
       hipLaunchKernelGGL((gn_apply_kernel<T, false, true>), dim3(grid_for(total, 256)), dim3(256), 0, st, (const T*)x1, c1, (const T*)x2,
-                         c2, coef, (T*)out, n, h, w, silu);
+                         c2, coef, (T*)out, n, h, w, silu, (f16_t*)raw_out);
     DTS_CHECK_LAUNCH("dts_gn_apply_x3");
     return DTS_OK;
   }

@@ -174,20 +174,28 @@ class EDMPrecond:
         G = self._groups
         ss = aff[:, P.aff_off:P.aff_off + P.caff]
         bnc = None if self.adm else ss
+        skip_src = None
         if self.fuse_gn and not b.down and ops.conv_fuses_gn(x1, P.w0, x2=x2, up=b.up):
             # norm0 + SiLU applied inside conv0 on its staged input tile: the normalised (and, in the decoder, concatenated) tensor
             # is never written (networks.py:168)
             coef = ops.gn_coefficients(x1, G(b.cin), self.eps, P.g0, P.b0, x2=x2)
             h = ops.conv2d(x1, P.w0, P.cb0, x2=x2, up=b.up, bias_nc=bnc, gn_stats=True, gn_coef=coef, gn_silu=True)
         else:
-            h = ops.group_norm(x1, G(b.cin), self.eps, P.g0, P.b0, x2=x2, silu=True, pool=b.down, split_out=self.x3)
+            # split-precision mode, blocks with a 1x1 skip convolution: the norm0 pass also writes the operand image of the RAW input
+            # (2x2-averaged in a down block), which the skip convolution reads -- no dts_split3_f16 pass over the same tensor
+            raw = self.x3 and P.skip_w is not None and os.environ.get('DTS_X3_RAW_SPLIT', '1') != '0'
+            h = ops.group_norm(x1, G(b.cin), self.eps, P.g0, P.b0, x2=x2, silu=True, pool=b.down, split_out=self.x3, raw_split=raw)
+            if raw:
+                h, skip_src = h
             h = ops.conv2d(h, P.w0, P.cb0, up=b.up, bias_nc=bnc, gn_stats=True)
         fuse1 = self.fuse_gn and ops.conv_fuses_gn(h, P.w1)
         if fuse1:        # norm1 (+ adaptive scale/shift) + SiLU inside conv1 (networks.py:173-175)
             coef1 = ops.gn_coefficients(h, G(b.cout), self.eps, P.g1, P.b1, scale_shift=ss if self.adm else None)
         else:
             h = ops.group_norm(h, G(b.cout), self.eps, P.g1, P.b1, scale_shift=ss if self.adm else None, silu=True, split_out=self.x3)
-        if P.skip_w is not None:
+        if P.skip_w is not None and skip_src is not None:
+            sk = ops.conv2d(skip_src, P.skip_w, P.skip_b, up=b.up)
+        elif P.skip_w is not None:
             src1, src2 = (ops.resample2x(x1, up=False), None) if b.down else (x1, x2)
             sk = ops.conv2d(src1, P.skip_w, P.skip_b, x2=src2, up=b.up)
         elif b.up or b.down:

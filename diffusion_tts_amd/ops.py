@@ -312,16 +312,18 @@ def gn_coef(x1, groups, eps, gamma, beta, *, x2=None, scale_shift=None):
     return coef
 
 
-def gn_apply(x1, coef, *, x2=None, silu=True, pool=False, split_out=False):
-    """split_out (float32 inputs only): the result leaves as the f16 split image a split-precision convolution reads (SplitAct)."""
+def gn_apply(x1, coef, *, x2=None, silu=True, pool=False, split_out=False, raw_split=False):
+    """split_out (float32 inputs only): the result leaves as the f16 split image a split-precision convolution reads (SplitAct).
+    raw_split (with split_out): returns (normalised image, image of the un-normalised [2x2-averaged if pool] input) from the one pass."""
     n, h, w, c1 = x1.shape
     c2 = 0 if x2 is None else x2.shape[-1]
     ho, wo = (h // 2, w // 2) if pool else (h, w)
     if split_out:
         out = torch.empty((n, ho, wo, 2 * (c1 + c2)), dtype=torch.float16, device=x1.device)
+        raw = torch.empty_like(out) if raw_split else None
         _call('dts_gn_apply_x3', _ptr(x1, 'x1', torch.float32), c1, _ptr(x2, 'x2', torch.float32), c2, _ptr(coef, 'coef', torch.float32),
-              _ptr(out), n, h, w, int(silu), int(pool))
-        return SplitAct(out, c1 + c2)
+              _ptr(out), _ptr(raw), n, h, w, int(silu), int(pool))
+        return (SplitAct(out, c1 + c2), SplitAct(raw, c1 + c2)) if raw_split else SplitAct(out, c1 + c2)
     out = torch.empty((n, ho, wo, c1 + c2), dtype=x1.dtype, device=x1.device)
     _call('dts_gn_apply', _ptr(x1, 'x1'), c1, _ptr(x2, 'x2', x1.dtype), c2, dt_code(x1.dtype),
           _ptr(coef, 'coef', torch.float32), _ptr(out), n, h, w, int(silu), int(pool))
@@ -355,9 +357,9 @@ def gn_coefficients(x1, groups, eps, gamma, beta, *, x2=None, scale_shift=None):
     return coef if coef is not None else gn_coef(x1, groups, eps, gamma, beta, x2=x2, scale_shift=scale_shift)
 
 
-def group_norm(x1, groups, eps, gamma, beta, *, x2=None, scale_shift=None, silu=True, pool=False, path=None, split_out=False):
+def group_norm(x1, groups, eps, gamma, beta, *, x2=None, scale_shift=None, silu=True, pool=False, path=None, split_out=False, raw_split=False):
     """GroupNorm [+ (1+scale), shift] [+ SiLU] [+ 2x2 average pool].  path: None = auto, 'fused' | 'split' (tests).
-    split_out: float32 in, SplitAct out (the operand form of a split-precision convolution)."""
+    split_out: float32 in, SplitAct out (the operand form of a split-precision convolution); raw_split (with split_out): a pair, see gn_apply."""
     n, h, w, c1 = x1.shape
     c2 = 0 if x2 is None else x2.shape[-1]
     cg = (c1 + c2) // groups
@@ -365,7 +367,7 @@ def group_norm(x1, groups, eps, gamma, beta, *, x2=None, scale_shift=None, silu=
     if path in (None, 'strips'):
         coef = _coef_from_strips(x1, x2, groups, eps, gamma, beta, scale_shift)
         if coef is not None:
-            return gn_apply(x1, coef, x2=x2, silu=silu, pool=pool, split_out=split_out)
+            return gn_apply(x1, coef, x2=x2, silu=silu, pool=pool, split_out=split_out, raw_split=raw_split)
     if path == 'strips':
         raise ValueError('strip statistics are not attached to the input(s)')
     if path is None:
@@ -379,7 +381,7 @@ def group_norm(x1, groups, eps, gamma, beta, *, x2=None, scale_shift=None, silu=
               _ptr(gamma, 'gamma', torch.float32), _ptr(beta, 'beta', torch.float32), ss_ptr, ss_ld, _ptr(out), int(silu))
         return out
     return gn_apply(x1, gn_coef(x1, groups, eps, gamma, beta, x2=x2, scale_shift=scale_shift), x2=x2, silu=silu, pool=pool,
-                    split_out=split_out)
+                    split_out=split_out, raw_split=raw_split)
 
 
 def resample2x(x, up):

@@ -380,10 +380,11 @@ def _mcts(L: _Loop, t_steps, x_next, labels, p, pre):
                         # row 0, so the denoiser sees four batch shapes and replays their captured HIP graphs instead of launching
                         # ~500 kernels one by one from the host for every odd size.  Rows are independent, so the live rows do not
                         # depend on the padding VALUES; they can depend on the padded batch SIZE in the last bits, because the conv
-                        # launchers choose the split-K factor / launch form from the row count (another fixed f32 summation order).
-                        # The f32 parity mode therefore runs its rollouts unpadded; padding rows are not counted as evaluations.
+                        # launchers choose the split-K factor / launch form from the row count (another fixed f32 summation order --
+                        # as is every batch size against the reference's batch-1 rollouts, edm/main.py:640-660).  The f32 parity mode,
+                        # the mode the others are measured against, runs its rollouts unpadded; padding rows are not counted as evaluations.
                         ka = len(act)
-                        pad = MCTS_PAD_ROLLOUTS and ka <= 16 and getattr(L.net, 'dtype', None) not in (torch.float32, ops.F16X3)
+                        pad = MCTS_PAD_ROLLOUTS and ka <= 16 and getattr(L.net, 'dtype', None) != torch.float32
                         kp = -(-ka // 4) * 4 if pad else ka
                         if kp > ka:
                             xa = torch.cat([xa, xa[:1].expand(kp - ka, *xa.shape[1:])], dim=0)

@@ -45,7 +45,7 @@ enum dts_status { DTS_OK = 0, DTS_ERR_ARG = -1, DTS_ERR_LAUNCH = -2, DTS_ERR_UNS
 #define DTS_ABI_VERSION 109        /* bumped with every change of a signature or of dts_conv_args (101: ev_start/ev_stop; 102: tuning knobs; 103: dts_cosine_rows; 104: dts_nchw_to_nhwc_pad,
                                      105: dts_conv_args.gn_coef / gn_silu, dts_conv_fuses_gn;
                                      head dim 512 in dts_attention; 106: dts_conv_kernel, 128-cout ping-pong blocks; 107: dts_resample_u8, dts_lut_u8_f32; 108: DTS_F16X3, dts_conv_args.acc_scale, dts_split3_f16, dts_gn_apply_x3, dts_split2_f16, dts_attention_x3;
-                                     109: dts_candidate_noise_sd; the DTS_F16X3 operand images are 2*C wide, interleaved per 32 channels) */
+                                     109: dts_candidate_noise_sd; the DTS_F16X3 operand images are 2*C wide, interleaved per 32 channels; dts_gn_apply_x3 raw_out) */
 int dts_version(void);            /* == DTS_ABI_VERSION of the build; a binding must refuse any other value */
 const char* dts_last_error(void);
 /* Tuning knobs (measurement aid; a knob only selects between kernels / block orders / ring depths that give correct results -- the
@@ -135,8 +135,10 @@ int dts_gn_apply(const void* x1, int c1, const void* x2, int c2, int dtype, cons
                  void* out, int n, int h, int w, int silu, int pool, dts_stream s);
 /* the same pass in the split-precision mode (DTS_F16X3): x / coef as above in f32, out = the f16 split image [n][h'][w'][2*C] (per 32
  * channels hi | lo * 2^11, the arithmetic and layout of dts_split3_f16) that dts_conv2d(dtype = DTS_F16X3) reads -- the f32 normalised
- * tensor is never written.  C a multiple of 32. */
-int dts_gn_apply_x3(const float* x1, int c1, const float* x2, int c2, const float* coef, void* out, int n, int h, int w, int silu,
+ * tensor is never written.  C a multiple of 32.  raw_out (optional, same shape as out): the split image of the UN-normalised input rows
+ * (2x2-averaged like dts_resample2x when pool = 1) is written by the same pass -- the operand of the block's 1x1 skip convolution
+ * (networks.py:177), bit-identical to dts_split3_f16 of the (resampled) input. */
+int dts_gn_apply_x3(const float* x1, int c1, const float* x2, int c2, const float* coef, void* out, void* raw_out, int n, int h, int w, int silu,
                     int pool, dts_stream s);
 /* single-launch variant for low-resolution levels (hw <= ~256): statistics + apply in one kernel, one block per
  * (group, sample); same result as dts_gn_coef + dts_gn_apply(pool=0).  Channels per group must be even and <= 64. */
