@@ -212,8 +212,10 @@ def conv_roofline(a, run_once, reps, dtype_name, value_per_gpu, gflop_per_eval, 
         es = out.element_size()
         cin = w.shape[3]
         # algorithmic bytes of the launch: every input / weight / residual byte read once, every output byte written once
-        alg = es * (x1.numel() + (kw['x2'].numel() if kw.get('x2') is not None else 0) + w.numel() + out.numel() +
-                    (out.numel() if kw.get('residual') is not None else 0))
+        # (split precision: the operand image is 4 bytes per logical input element like the f32 tensor it stands for, the packed weight 2 x f16)
+        wbytes = w.packed.numel() * 2 if isinstance(w, ops.X3Weight) else w.numel() * es
+        alg = es * (x1.numel() + (kw['x2'].numel() if kw.get('x2') is not None else 0) + out.numel() +
+                    (out.numel() if kw.get('residual') is not None else 0)) + wbytes
         # which kernel the launcher picks (csrc/conv_igemm.hip conv_pick_pp via dts_conv_kernel): the names a kernel trace shows
         kern = ops.conv_kernel(x1, w, x2=kw.get('x2'), up=bool(kw.get('up')), residual=kw.get('residual'), gn_coef=kw.get('gn_coef'))
         fam = {6: 'conv_pp_kernel', 4: 'conv_pp_kernel/128'}.get(kern) or ('conv_igemm_kernel/3x3' if w.shape[1] == 3 else 'conv_igemm_kernel/1x1')

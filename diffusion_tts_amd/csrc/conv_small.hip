@@ -90,7 +90,8 @@ template <typename T, int NT>
 __global__ __launch_bounds__(256) void conv_in3_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, T* __restrict__ out, int nseg, int h,
                                                              int wd) {
-  constexpr int COUT = NT * 16, ROWB = COUT * 2 + 16, TG = 4;           // TG independent accumulator tiles in flight
+  constexpr int ES = sizeof(T) == 4 ? 4 : 2;                            // f32 outputs (round 5: the f32 / split-precision modes took the VALU kernel above, 170 us per 64-row launch)
+  constexpr int COUT = NT * 16, ROWB = COUT * ES + 16, TG = 4;          // TG independent accumulator tiles in flight
   static_assert(NT % TG == 0, "tile groups");
   __shared__ __attribute__((aligned(16))) char stage_all[4 * 16 * ROWB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, p = lane & 15, kq = lane >> 4;
@@ -138,17 +139,21 @@ __global__ __launch_bounds__(256) void conv_in3_mfma_kernel(const float* __restr
         for (int u = 0; u < TG; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t0 + u][s], bv[s], acc[u], 0, 0, 0);
 #pragma unroll
       for (int u = 0; u < TG; ++u) {
-        uint2 o;
-        if (std::is_same<T, bf16_t>::value) { o.x = pack2_bf16(acc[u][0], acc[u][1]); o.y = pack2_bf16(acc[u][2], acc[u][3]); }
-        else { o.x = pack2_f16(acc[u][0], acc[u][1]); o.y = pack2_f16(acc[u][2], acc[u][3]); }
-        *reinterpret_cast<uint2*>(stage + p * ROWB + (16 * (t0 + u) + 4 * kq) * 2) = o;
+        if constexpr (std::is_same<T, float>::value) {
+          *reinterpret_cast<f32x4_t*>(stage + p * ROWB + (16 * (t0 + u) + 4 * kq) * 4) = acc[u];
+        } else {
+          uint2 o;
+          if (std::is_same<T, bf16_t>::value) { o.x = pack2_bf16(acc[u][0], acc[u][1]); o.y = pack2_bf16(acc[u][2], acc[u][3]); }
+          else { o.x = pack2_f16(acc[u][0], acc[u][1]); o.y = pack2_f16(acc[u][2], acc[u][3]); }
+          *reinterpret_cast<uint2*>(stage + p * ROWB + (16 * (t0 + u) + 4 * kq) * 2) = o;
+        }
       }
     }
     // the slab is wave-private and a wave's LDS operations complete in order: no barrier
     char* dst = reinterpret_cast<char*>(out + (size_t)seg * 16 * COUT);
 #pragma unroll
-    for (int c = lane; c < 2 * COUT; c += 64) {
-      const int px = c / (COUT / 8), ch = c - px * (COUT / 8);
+    for (int c = lane; c < COUT * ES; c += 64) {          // 16 pixels x COUT * ES bytes in 16-byte pieces
+      const int px = c / (COUT * ES / 16), ch = c - px * (COUT * ES / 16);
       *reinterpret_cast<uint4*>(dst + (size_t)c * 16) = *reinterpret_cast<const uint4*>(stage + px * ROWB + ch * 16);
     }
   }
@@ -219,7 +224,7 @@ extern "C" int dts_conv_in3(const float* x, const float* w, const float* bias, v
   DTS_CHECK_ARG(n > 0 && h > 0 && w_ > 0 && cout % 8 == 0 && cout <= 512, "dts_conv_in3: bad shape (cout=%d)", cout);
   hipStream_t st = to_stream(s);
   const long long nseg = (long long)n * h * (w_ / 16);
-  if (dtype != DTS_F32 && w_ % 16 == 0 && (cout == 192 || cout == 128 || cout == 64) && nseg < (1ll << 31) &&
+  if (w_ % 16 == 0 && (cout == 192 || cout == 128 || cout == 64) && nseg < (1ll << 31) &&
       (bias == nullptr || ((uintptr_t)bias & 15) == 0)) {
     // up to 8 segments per wave (the 7*NT weight registers are loaded once per wave), fewer when that would leave CUs idle
     long long spw = nseg / 2048;
@@ -231,6 +236,8 @@ extern "C" int dts_conv_in3(const float* x, const float* w, const float* bias, v
   hipLaunchKernelGGL((conv_in3_mfma_kernel<TT, NT_>), dim3((int)g), dim3(256), 0, st, x, w, bias, (TT*)out, (int)nseg, h, w_)
     if (dtype == DTS_BF16) {
       if (cout == 192) DTS_IN3_MFMA(bf16_t, 12); else if (cout == 128) DTS_IN3_MFMA(bf16_t, 8); else DTS_IN3_MFMA(bf16_t, 4);
+    } else if (dtype == DTS_F32) {
+      if (cout == 192) DTS_IN3_MFMA(float, 12); else if (cout == 128) DTS_IN3_MFMA(float, 8); else DTS_IN3_MFMA(float, 4);
     } else {
       if (cout == 192) DTS_IN3_MFMA(f16_t, 12); else if (cout == 128) DTS_IN3_MFMA(f16_t, 8); else DTS_IN3_MFMA(f16_t, 4);
     }

@@ -12,6 +12,8 @@ cp "$(ls -t $O/final_prof_c8/*/*kernel_stats.csv | head -1)" profiles/${RD}_c8_k
 python tools/rocprof_dominant.py profiles/${RD}_bench_kernel_stats.csv f16x3 profiles/${RD}_rocprof_dominant_f16x3.json $HEAD
 python tools/rocprof_dominant.py profiles/${RD}_bf16_kernel_stats.csv bf16 profiles/${RD}_rocprof_dominant_bf16.json $HEAD
 grep "^{" $O/final_bench.json > profiles/${RD}_bench.json
+python tools/pmc_traffic.py $O/final_pmc_fetch_f16x3 $O/final_pmc_write_f16x3 $O/final_hbm_traffic_pmc_f16x3.json $O/final_conv_sequence.json > $O/final_pmc_per_shape_f16x3.txt 2>&1
+python tools/pmc_traffic.py $O/final_pmc_fetch_bf16 $O/final_pmc_write_bf16 $O/final_hbm_traffic_pmc_bf16.json $O/final_conv_sequence_bf16.json > $O/final_pmc_per_shape_bf16.txt 2>&1
 for dt in f16x3 bf16; do
 python - $O/final_hbm_traffic_pmc_$dt.json profiles/${RD}_hbm_traffic_pmc_$dt.json $HEAD $dt <<'PY'
 import json, sys
@@ -57,7 +59,8 @@ out = {'dtype': d['dtype'], 'kernel': rp['kernel'], 'rocprofv3_avg_launch_us': r
               'kernel\'s own dispatch in the default bench.py run.  FLOPs are ALGORITHMIC (f16x3: x3 for the matrix work)'}
 try:      # the SAME profiled process measured both ways (final_profiles.sh: final_prof_both)
     b = json.loads([l for l in open('gpurun_out/final_prof_both.json') if l.startswith('{')][-1])['roofline']
-    rows2 = list(csv.DictReader(open(sorted(glob.glob('gpurun_out/final_prof_both/*/*kernel_stats.csv'))[-1])))
+    import os
+    rows2 = list(csv.DictReader(open(max(glob.glob('gpurun_out/final_prof_both/*/*kernel_stats.csv'), key=os.path.getmtime))))
     dom2 = [x for x in rows2 if rp['kernel'] in x['Name']][0]
     out['same_process'] = {'in_process_avg_launch_us': b['avg_launch_us'], 'rocprofv3_avg_launch_us': round(float(dom2['AverageNs']) / 1e3, 2),
                            'ratio': round(float(dom2['AverageNs']) / 1e3 / b['avg_launch_us'], 4), 'frac_in_process': b['frac'],

@@ -1,8 +1,7 @@
 #!/bin/bash
 # The round's evidence run, part B (a second gpurun call, ~12 min): rocprofv3 kernel statistics of the bench command in the headline mode
 # (f16x3), in bf16 and at 8 candidates per GPU, the SAME process measured both ways (in-process dispatch events vs the trace), and the two
-# PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs, --kernel-trace only) for HBM traffic in f16x3 and in bf16.  Needs part A's
-# gpurun_out/final_conv_sequence*.json for the per-shape table (merged back into gpurun_out/ by gpurun, so it travels with the next call).
+# PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs, --kernel-trace only) for HBM traffic in f16x3 and in bf16.
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 python tools/vae_bench.py --n 16 > $O/final_vae.txt 2>&1 || exit 1
@@ -20,7 +19,7 @@ for dt in f16x3 bf16; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/final_pmc_write_$dt -- python3 $R/bench.py --steps 2 --warmup 1 --dtype $dt $Q > $O/final_pmc_write_$dt.log 2>&1 || exit 1
 done
 cd $R
-python tools/pmc_traffic.py $O/final_pmc_fetch_f16x3 $O/final_pmc_write_f16x3 $O/final_hbm_traffic_pmc_f16x3.json $O/final_conv_sequence.json > $O/final_pmc_per_shape_f16x3.txt 2>&1
-python tools/pmc_traffic.py $O/final_pmc_fetch_bf16 $O/final_pmc_write_bf16 $O/final_hbm_traffic_pmc_bf16.json $O/final_conv_sequence_bf16.json > $O/final_pmc_per_shape_bf16.txt 2>&1
-find $O -name "*kernel_trace.csv" -size +20M -delete; find $O -name "*counter_collection.csv" -size +20M -delete; find $O -name "*.db" -delete
-head -5 $O/final_pmc_per_shape_f16x3.txt; ls $O/final_prof_x3/*/ | head
+# (the per-shape join with part A's gpurun_out/final_conv_sequence*.json happens in tools/collect_profiles.sh, in the build container: gpurun_out/ does
+#  not travel to the GPU box, the counter CSVs come back)
+find $O -name "*kernel_trace.csv" -size +20M -delete; find $O -name "*counter_collection.csv" -size +30M -delete; find $O -name "*.db" -delete
+ls $O/final_prof_x3/*/ $O/final_pmc_fetch_f16x3/*/ | head

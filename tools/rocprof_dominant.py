@@ -14,6 +14,11 @@ PAT = {'bf16': 'conv_pp_kernel<bf16_t, 9, 0, false, 6, bf16_t>', 'f16': 'conv_pp
        'f16x3': 'conv_pp_kernel<f16_t, 9, 0, false, 6, float>'}
 
 
+def short(name):
+    import re
+    return re.sub(r'\(ConvP\)$|\(AttP\)$', '', name.replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', ''))
+
+
 def main():
     stats, dtype, out = sys.argv[1:4]
     commit = sys.argv[4] if len(sys.argv) > 4 else 'unknown'
@@ -23,11 +28,11 @@ def main():
     if not dom:          # older name form without the output-type argument
         dom = [r for r in rows if PAT[dtype].rsplit(',', 1)[0] in r['Name']]
     r = dom[0]
-    doc = {'kernel_family': 'conv_pp_kernel', 'kernel': r['Name'].split('(')[0].replace('void (anonymous namespace)::', ''), 'dtype': dtype,
+    doc = {'kernel_family': 'conv_pp_kernel', 'kernel': short(r['Name']), 'dtype': dtype,
            'calls': int(r['Calls']), 'avg_launch_us': round(float(r['AverageNs']) / 1e3, 3), 'share_of_kernel_time': round(float(r['TotalDurationNs']) / tot, 4),
            'collected_at_commit': commit,
            'command': 'rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --dtype %s --no-cpu-baseline --no-kernel-timing --no-e2e --no-parity --no-subrecords' % dtype,
-           'top_kernels': [{'name': x['Name'].split('(')[0].replace('void (anonymous namespace)::', '')[:90], 'calls': int(x['Calls']),
+           'top_kernels': [{'name': short(x['Name'])[:90], 'calls': int(x['Calls']),
                             'avg_us': round(float(x['AverageNs']) / 1e3, 2), 'pct': float(x['Percentage'])} for x in rows[:12]]}
     json.dump(doc, open(out, 'w'), indent=1)
     print(doc['kernel'], doc['calls'], 'calls', doc['avg_launch_us'], 'us', f"{100 * doc['share_of_kernel_time']:.1f} % of kernel time")
