@@ -1225,13 +1225,9 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
       //   2: the pieces first, then the fragment reads (shipped)                                        1109
       // DBG 6 / 7 build orders 1 / 2 whatever the default (tools/conv_bench.py conv_variant=61 / 71).
       constexpr int LOAD_ORDER = DBG == 6 ? 1 : (DBG == 7 ? 2 : PP_LOAD_ORDER);
-      // DBG 9 = the former order (all 20 fragment reads in LOAD), kept for the A/B: conv_variant=91.  X3I: with 72 MFMAs per tile COMPUTE paces the
-      // loop again (stamps: COMPUTE 1 391 own cycles against LOAD 1 225), so the six reads go back to LOAD unless PP_X3_GA_LATE is defined (A/B build)
-#ifdef PP_X3_GA_LATE
+      // DBG 9 = the former order (all 20 fragment reads in LOAD), kept for the A/B: conv_variant=91.  (X3I, round 5: with 72 MFMAs per tile the
+      // six late reads were moved back into LOAD as an A/B: 1 374 vs 1 376 evals/s on one box, 228 instead of 206 VGPRs -- no difference, not kept.)
       constexpr bool GA_LATE = DBG != 9;
-#else
-      constexpr bool GA_LATE = DBG != 9 && !X3I;
-#endif
       if constexpr (LOAD_ORDER != 2) {
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
