@@ -456,3 +456,42 @@ def test_config3_n64_search_matches_the_reference_run(golden_full, manifest_full
     assert diff.max() <= 1 and (diff > 0).mean() < 0.005
     print(f'  final state vs the reference: max |x - x_ref| = {x_err:.2e}')
     assert x_err < 1e-3                                              # north_star: final images within 1e-3 abs
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, X3])
+def test_config3_n64_longer_search_matches_the_reference_run(golden_full, manifest_full, dtype):
+    """The same comparison over a search that carries state through several decisions: the reference's own generate_image_grid run with the
+    full ADM-64 + classifier, N = 64, K = 2, three sigma steps (3, 0.19, 0.002), 645 denoiser rows: 6 decisions -- four with top-2 gaps
+    >= 5e-8 whose winners become the next pivot / state, two exact 64-way ties at sigma 0.002 -- every reward vector, every selected index, the row
+    count, the final state and the PNG.  No oracle in between: free-running GPU search against free-running reference search."""
+    if 'eg64long' not in manifest_full:
+        pytest.skip('fullsize golden without the long search (DTS_GOLDEN_LONG=0)')
+    from helpers import full_weights
+    from diffusion_tts_amd import sampler as sm, scorers as S
+    from diffusion_tts_amd.hashing import seed0_scale
+    from diffusion_tts_amd.networks import EDMPrecond
+    m = manifest_full['eg64long']
+    cfg, sd = full_weights(manifest_full, 'adm_imagenet64')
+    ccfg, csd = full_weights(manifest_full, 'cls_imagenet64')
+    net = EDMPrecond(cfg, sd, device=DEV, dtype=dtype)
+    scorer = S.ImageNetScorer(weights=csd, cfg=ccfg, device=DEV, compute_dtype=dtype)
+    lat = torch.from_numpy(golden_full['eg64_latents'])
+    lab = torch.eye(1000)[torch.from_numpy(golden_full['eg64_label_idx']).long()]
+    h = sm.generate_image_grid(net, None, lat, lab, seed=m['seed'], gridw=1, gridh=1, device=torch.device(DEV), num_steps=m['num_steps'],
+                               sigma_max=m['sigma_max'], sampling_method=sm.SamplingMethod.EPS_GREEDY,
+                               sampling_params=dict(scorer=scorer, **m['params']), scale_fn=seed0_scale, compute_dtype=dtype, verbose=False, **m['S'])
+    assert h['net_rows'] == m['net_rows'] and len(h['rewards']) == 6
+    errs = []
+    for j in range(6):
+        got, ref = h['rewards'][j].reshape(-1).numpy(), golden_full[f'eg64long_rewards{j}']
+        errs.append(float(np.abs(got - ref).max()))
+        assert int(h['selected'][j][0]) == int(golden_full['eg64long_selected'][j]) == m['selected'][j], (j, h['selected'][j], m['selected'])
+    gaps = [g_ for g_ in m['top2_gaps'] if g_ > 0]
+    x_err = float((h['x'].cpu() - torch.from_numpy(golden_full['eg64long_last_D']).double()).abs().max())
+    print(f'config 3, N=64, K=2, three steps vs the reference run, {dtype}: reward errs {errs}, reference top-2 gaps {m["top2_gaps"]}, selected {m["selected"]}, '
+          f'max |x - x_ref| {x_err:.2e}')
+    assert max(errs) < 5e-8 and min(gaps) > 3 * max(errs)
+    assert abs(float(h['final_scores'][0]) - float(golden_full['eg64long_final_score'][0])) < 5e-8 and x_err < 1e-3
+    img = h['image'][0].permute(1, 2, 0).numpy().astype(np.int32)
+    diff = np.abs(img - golden_full['eg64long_image'].astype(np.int32))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.005
