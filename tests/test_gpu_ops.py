@@ -227,6 +227,15 @@ def test_group_norm_split_precision_output(ops, variant):
     wt = torch.randn(64, C_, 1, 1, generator=gen) / math.sqrt(C_)
     w3 = ops.pack_conv_weight(wt.to(DEV), ops.F16X3)
     assert float((ops.conv2d(sp, w3) - ops.conv2d(plain, w3)).abs().max()) < 1e-5
+    # raw_split: the same pass also writes the operand image of the UN-normalised input (2x2-averaged in the pooled form, with
+    # dts_resample2x's arithmetic) -- what the block's 1x1 skip convolution reads: bit for bit dts_split3_f16 of the (resampled) input
+    sp2, raw = ops.group_norm(x1, 32, 1e-5, gamma, beta, split_out=True, raw_split=True, **kw)
+    assert torch.equal(sp2.data, sp.data) and isinstance(raw, ops.SplitAct) and tuple(raw.shape) == tuple(plain.shape)
+    if variant == 'pool':
+        want = ops.split3_f16(ops.resample2x(x1, up=False))
+    else:
+        want = ops.split3_f16(x1, x2)
+    assert torch.equal(raw.data, want), int((raw.data != want).sum())
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
