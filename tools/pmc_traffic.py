@@ -13,8 +13,14 @@ import os
 import sys
 
 
-def per_kernel(directory, counter):
+def newest(directory):
+    """the counter file of the LATEST run under `directory` (gpurun merges every call's files into the same local folder)"""
     files = glob.glob(os.path.join(directory, '**', '*counter_collection.csv'), recursive=True)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
+def per_kernel(directory, counter):
+    files = newest(directory)
     if not files:
         raise SystemExit(f'no counter_collection.csv under {directory}')
     tot, cnt = collections.defaultdict(float), collections.defaultdict(int)
@@ -30,7 +36,7 @@ def per_kernel(directory, counter):
 def conv_dispatches(directory, counter):
     """(kernel family, value) of every conv dispatch in dispatch order."""
     out = []
-    for f in glob.glob(os.path.join(directory, '**', '*counter_collection.csv'), recursive=True):
+    for f in newest(directory):
         for r in csv.DictReader(open(f)):
             if r['Counter_Name'] != counter:
                 continue
