@@ -477,7 +477,14 @@ def test_conv_in3_out3(ops, dtype):
     w3 = torch.randn(3, 64, 3, 3, generator=gen) / 24
     b3 = torch.randn(3, generator=gen)
     got = ops.conv_out3(to_nhwc(ops, y, dtype), w3.permute(0, 2, 3, 1).contiguous().to(DEV), b3.to(DEV)).cpu()
-    assert rel_err(got, onet.conv2d(y, w3, b3)) < 1e-5
+    assert rel_err(got, onet.conv2d(y, w3, b3)) < 1e-5                 # 16 x 16: the tiled kernel (halo through LDS, scalar-cache weights)
+    y2 = q(torch.randn(3, 64, 12, 20, generator=gen), dtype)             # not multiples of 16: the direct kernel
+    got2 = ops.conv_out3(to_nhwc(ops, y2, dtype), w3.permute(0, 2, 3, 1).contiguous().to(DEV), b3.to(DEV)).cpu()
+    assert rel_err(got2, onet.conv2d(y2, w3, b3)) < 1e-5
+    y3 = q(torch.randn(2, 192, 32, 48, generator=gen), dtype)            # several patches per image, 192 channels (the ADM output conv's width)
+    w4 = torch.randn(3, 192, 3, 3, generator=gen) / 40
+    got3 = ops.conv_out3(to_nhwc(ops, y3, dtype), w4.permute(0, 2, 3, 1).contiguous().to(DEV), None).cpu()
+    assert rel_err(got3, onet.conv2d(y3, w4, None)) < 1e-5
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
