@@ -15,7 +15,7 @@ import math
 import os
 from dataclasses import dataclass, field
 from enum import Enum, auto
-from typing import Any, Callable, Dict, Optional
+from typing import Any, Callable, Dict, Optional, Sequence
 
 import numpy as np
 import torch
@@ -86,6 +86,7 @@ class _Loop:
         self.rewards, self.selected = [], []
         self.record_noises, self.best_noises = False, {}
         self.reuse_winner = False
+        self.forced = None                    # generate_image_grid(forced_selections=...)
 
     def up(self, t, dtype=None):
         return t.to(self.dev, dtype).contiguous() if dtype is not None else t.to(self.dev).contiguous()
@@ -268,6 +269,8 @@ def _eps_greedy(L: _Loop, t_steps, x_next, labels, p, pre):
             best = scores.argmax(dim=0)                                                # first max (:842)
             L.rewards.append(scores)
             L.selected.append(best)
+            if L.forced is not None:                                                   # follow another run's trajectory (B == 1)
+                best = torch.tensor([L.forced[len(L.selected) - 1]])
             # survivor rebuilt from the replicated host noise: no second collective
             bl = best.tolist()
             g_w = torch.stack([g_h[j][b] for b, j in enumerate(bl)])
@@ -433,11 +436,15 @@ def generate_image_grid(
     precomputed_noise: Optional[Dict[Any, torch.Tensor]] = None,
     *, scale_fn: Callable[[int, int, int], float] = builtin_scale, compute_dtype=ops.F16X3, verbose=True,
     reuse_winner: Optional[bool] = None, record_noises: bool = False, shard_candidates: bool = True,
+    forced_selections: Optional[Sequence[int]] = None,
 ):
     """Same positional/keyword surface as edm/main.py:47-55.  Keyword-only extras: `scale_fn` (the hash-derived step
     table, edm/main.py:776), `compute_dtype` (default ops.F16X3: split precision, the reference's fp32 selections at a third of the 16-bit
     rate; float32 = parity mode on the f32 matrix instruction; bfloat16 / float16 = throughput modes), `verbose`, `reuse_winner` (see below), `record_noises`
-    (keep the per-iteration winning noises for `dump_noise_trajectory`; costs one D2H copy per iteration).  Writes the PNG grid like the
+    (keep the per-iteration winning noises for `dump_noise_trajectory`; costs one D2H copy per iteration), `forced_selections` (eps-greedy /
+    zero-order, one image: decision d continues from candidate forced_selections[d] instead of its own argmax, which is still what
+    `selected` records -- how a search is walked along ANOTHER run's trajectory so that every decision of the two stays comparable; the
+    parity tests follow the reference's recorded run this way).  Writes the PNG grid like the
     reference when `dest_path` is not None and additionally returns a dict with the final state and the search trace."""
     device = torch.device(device)
     if device.type != 'cuda':
@@ -457,6 +464,10 @@ def generate_image_grid(
     # `net_rows` equals the reference's count (config 3: 8 995); the 16-bit throughput modes reuse the row (8 960 rows, same values).
     L.reuse_winner = (compute_dtype not in (torch.float32, ops.F16X3)) if reuse_winner is None else bool(reuse_winner)
     L.record_noises = bool(record_noises)
+    if forced_selections is not None:
+        if sampling_method not in (SamplingMethod.EPS_GREEDY, SamplingMethod.ZERO_ORDER) or latents.shape[0] != 1:
+            raise ValueError('forced_selections: eps-greedy / zero-order search of one image only')
+        L.forced = [int(v) for v in forced_selections]
     x0 = (latents.to(torch.float64).cpu() * t_steps[0]).to(device).contiguous()       # edm/main.py:99
     labels = None if class_labels is None else class_labels.to(device, torch.float32).contiguous()
     evals0 = getattr(net, 'evals', 0)

@@ -35,3 +35,21 @@ def golden_full():
 def manifest_full():
     with open(os.path.join(ROOT, 'tests', 'golden', 'fullsize_manifest.json')) as f:
         return json.load(f)
+
+
+@pytest.fixture(scope='session')
+def golden_c3():
+    """the reference's own run of BASELINE configs[2] end to end (tests/golden/make_golden_config3.py, ~1.5 h of CPU)"""
+    p = os.path.join(ROOT, 'tests', 'golden', 'config3_golden.npz')
+    if not os.path.exists(p):
+        pytest.skip('tests/golden/config3_golden.npz not generated')
+    return np.load(p)
+
+
+@pytest.fixture(scope='session')
+def manifest_c3():
+    p = os.path.join(ROOT, 'tests', 'golden', 'config3_manifest.json')
+    if not os.path.exists(p):
+        pytest.skip('tests/golden/config3_manifest.json not generated')
+    with open(p) as f:
+        return json.load(f)

@@ -495,3 +495,75 @@ def test_config3_n64_longer_search_matches_the_reference_run(golden_full, manife
     img = h['image'][0].permute(1, 2, 0).numpy().astype(np.int32)
     diff = np.abs(img - golden_full['eg64long_image'].astype(np.int32))
     assert diff.max() <= 1 and (diff > 0).mean() < 0.005
+
+
+@pytest.mark.parametrize('dtype', [X3, torch.float32])
+def test_config3_whole_search_against_the_reference_run(golden_full, manifest_full, golden_c3, manifest_c3, dtype):
+    """BASELINE.json configs[2] END TO END against THE REFERENCE'S OWN RUN of it (edm/main.py generate_image_grid on the CPU of the build
+    container: EPS_GREEDY, N = 64, K = 4, 18 sigma steps, full ADM-64 + full classifier, 8 995 denoiser rows, 72 decisions; no oracle in
+    between).  Two searches per parity-grade mode, from the same host RNG:
+      (1) walked along the reference's recorded selections (forced_selections), so all 72 decisions see the reference's candidates: every
+          reward vector to 5e-8, the build's OWN argmax equal to the reference's wherever the reference's top-2 gap exceeds 4x the measured
+          reward error (exact ties -- no churn noise at sigma > 50 and < 0.05, all candidates identical -- must be exact ties here too and
+          fall to index 0 by the first-max rule), the row count, the final state within 1e-3 (north_star), the PNG within 1 LSB;
+      (2) free-running: the same 72 selections and the same final image; a difference is accepted only at a decision the reference itself
+          decided by less than 4x the reward error, i.e. where two correct fp32 summation orders disagree."""
+    from helpers import full_weights
+    from diffusion_tts_amd import sampler as sm, scorers as S
+    from diffusion_tts_amd.hashing import seed0_scale
+    from diffusion_tts_amd.networks import EDMPrecond
+    m = manifest_c3
+    assert m['num_steps'] == 18 and m['params'] == dict(N=64, K=4, lambda_param=0.15, eps=0.4) and m['net_rows'] == 8995
+    assert m['adm_imagenet64']['checksum'] == manifest_full['adm_imagenet64']['checksum'] and m['cls_checksum'] == manifest_full['cls_imagenet64']['checksum']
+    cfg, sd = full_weights(manifest_full, 'adm_imagenet64')
+    ccfg, csd = full_weights(manifest_full, 'cls_imagenet64')
+    net = EDMPrecond(cfg, sd, device=DEV, dtype=dtype)
+    scorer = S.ImageNetScorer(weights=csd, cfg=ccfg, device=DEV, compute_dtype=dtype)
+    lat = torch.from_numpy(golden_full['eg64_latents'])
+    lab = torch.eye(1000)[torch.from_numpy(golden_full['eg64_label_idx']).long()]
+    ref_rew, ref_sel = golden_c3['rewards'], [int(v) for v in golden_c3['selected']]
+    gaps = m['top2_gaps']
+    assert ref_rew.shape == (72, 64) and ref_sel == m['selected']
+
+    def search(forced):
+        h = sm.generate_image_grid(net, None, lat, lab, seed=m['seed'], gridw=1, gridh=1, device=torch.device(DEV), num_steps=18,
+                                   sampling_method=sm.SamplingMethod.EPS_GREEDY, sampling_params=dict(scorer=scorer, **m['params']),
+                                   scale_fn=seed0_scale, compute_dtype=dtype, verbose=False, forced_selections=forced, **m['S'])
+        assert h['net_rows'] == m['net_rows'] and len(h['rewards']) == 72
+        return h, np.stack([r.reshape(-1).numpy() for r in h['rewards']]), [int(s_[0]) for s_ in h['selected']]
+
+    def final_checks(h, tag):
+        x_err = float((h['x'].cpu() - torch.from_numpy(golden_c3['last_D']).double()).abs().max())
+        img = h['image'][0].permute(1, 2, 0).numpy().astype(np.int32)
+        diff = np.abs(img - golden_c3['image'].astype(np.int32))
+        ds = abs(float(h['final_scores'][0]) - float(golden_c3['final_score'][0]))
+        print(f'  {tag}: max |x_final - x_final(reference)| = {x_err:.2e}, PNG pixels off by one: {int((diff > 0).sum())} of {diff.size}, final score off by {ds:.1e}')
+        assert x_err < 1e-3 and diff.max() <= 1 and (diff > 0).mean() < 0.005 and ds < 5e-8
+
+    # (1) along the reference's trajectory
+    h, rew, own = search(ref_sel)
+    errs = np.abs(rew.astype(np.float64) - ref_rew.astype(np.float64)).max(axis=1)
+    decidable = 0
+    for d in range(72):
+        if gaps[d] == 0.0:
+            assert np.all(rew[d] == rew[d][0]) and own[d] == ref_sel[d] == 0, (d, own[d], ref_sel[d])
+        elif gaps[d] > 4 * errs[d]:
+            decidable += 1
+            assert own[d] == ref_sel[d], (d, own[d], ref_sel[d], gaps[d], errs[d])
+    nz = [g_ for g_ in gaps if g_ > 0]
+    print(f'config 3 whole search vs the reference run, {dtype}: max reward error {errs.max():.2e} over 72 x 64 rewards; {len(gaps) - len(nz)} exact ties; '
+          f'{decidable} of {len(nz)} other decisions decidable (reference top-2 gap > 4x error; smallest gap {min(nz):.2e}); own argmax == reference at '
+          f'{sum(int(a_ == b_) for a_, b_ in zip(own, ref_sel))}/72')
+    assert errs.max() < 5e-8 and decidable >= 40
+    final_checks(h, 'walked along the reference selections')
+    # (2) free-running
+    hf, rewf, ownf = search(None)
+    same = [int(a_ == b_) for a_, b_ in zip(ownf, ref_sel)]
+    print(f'  free-running: {sum(same)}/72 selections equal to the reference run')
+    if 0 in same:
+        first = same.index(0)
+        e = float(np.abs(rewf[first].astype(np.float64) - ref_rew[first].astype(np.float64)).max())
+        print(f'  first differing selection {first}: reference top-2 gap {gaps[first]:.2e}, reward error there {e:.2e}')
+        assert gaps[first] <= 4 * max(e, float(errs.max())), (first, gaps[first], e)
+    else:
+        final_checks(hf, 'free-running')
