@@ -175,3 +175,38 @@ def test_fullsize_eps_greedy_n64_first_decision_matches_reference(golden_full, m
     print(f'oracle vs reference, config-3 N=64 decision 0: max reward err {err:.2e}, reference top-2 gap {m["top2_gaps"][0]:.2e}, argmax {int(got.argmax())}')
     assert err < 5e-8 and m['top2_gaps'][0] > 4 * err
     assert int(got.argmax()) == int(golden_full['eg64_selected'][0]) == m['selected'][0]
+
+
+def test_config3_reference_run_golden_is_consistent_and_the_oracle_scores_its_final_image(golden_full, manifest_full, golden_c3, manifest_c3):
+    """tests/golden/config3_golden.npz (the reference's own end-to-end run of BASELINE configs[2]; the GPU suite compares whole searches with
+    it): 72 decisions x 64 rewards, `selected` = first argmax, the exact ties are where no churn noise is drawn (sigma > 50, < 0.05), the 8 995
+    denoiser rows are counted below, the PNG is the quantised final state (edm/main.py:869), and the ORACLE's
+    denoiser + scorer reproduce the reference's last denoiser call and final score from the stored inputs (one full-size row each)."""
+    from helpers import full_weights
+    m, g = manifest_c3, golden_c3
+    rew, sel = g['rewards'], [int(v) for v in g['selected']]
+    assert rew.shape == (72, 64) and rew.dtype == np.float32 and sel == m['selected'] == [int(r.argmax()) for r in rew]
+    # rows (edm/main.py:749-860): per sigma step K candidate batches of N rows + the batch-1 step of the final pivot, two denoiser calls each
+    # (Heun), one at the last step (Euler to sigma = 0)
+    N, K = m['params']['N'], m['params']['K']
+    assert m['net_rows'] == 17 * 2 * (K * N + 1) + (K * N + 1) == 8995 and m['scorer_calls'] == 73
+    sig = g['sigmas']
+    assert len(sig) >= 18 and abs(sig[0] - 80.0) < 1e-9 and abs(sig[-1] - 0.002) < 1e-9      # every sigma a denoiser call saw, descending
+    ties = [d for d in range(72) if m['top2_gaps'][d] == 0.0]
+    for d in ties:
+        assert np.all(rew[d] == rew[d][0]) and sel[d] == 0                      # identical candidates, first-max rule
+    assert m['exact_ties'] == len(ties) and all(d < 8 or d >= 60 for d in ties)   # steps 0-1 (sigma 80, 57.6) and 15-17 (sigma < 0.05)
+    assert m['adm_imagenet64']['checksum'] == manifest_full['adm_imagenet64']['checksum']
+    # the final state is the last call's output (x_next = x_hat + (0 - t) * (x_hat - D) / t), the PNG its quantisation
+    D = g['last_D'][0].astype(np.float64)
+    img = np.clip(D * 127.5 + 128, 0, 255).astype(np.uint8).transpose(1, 2, 0)
+    assert np.array_equal(img, g['image'])
+    torch.set_num_threads(8)
+    cfg, sd = full_weights(manifest_full, 'adm_imagenet64')
+    ccfg, csd = full_weights(manifest_full, 'cls_imagenet64')
+    lab = torch.eye(1000)[T(golden_full['eg64_label_idx']).long()]
+    got = oracle_net(cfg, sd)(T(g['last_x']), torch.tensor([float(sig[-1])], dtype=torch.float64), lab)
+    err = float((got - T(g['last_D'])).abs().max())
+    sc = oscore.ImageNetOracle(oracle_cls_cfg(ccfg), csd)(torch.from_numpy(img.transpose(2, 0, 1)[None].copy()), lab, torch.zeros(1))
+    print(f'oracle on the reference run\'s last step: max |D - D_ref| = {err:.2e}; final score {float(sc[0]):.6e} vs {float(g["final_score"][0]):.6e}')
+    assert err < 2e-5 and abs(float(sc[0]) - float(g['final_score'][0])) < 5e-8
