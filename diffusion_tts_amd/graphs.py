@@ -5,6 +5,9 @@ every iteration (edm/main.py:842) drains the queue, so each iteration restarts l
 every 44 ms, and at the small per-GPU batches of a sharded search the host, not the GPU, set the pace.  The forward of a given
 (batch, dtype) is a fixed kernel sequence with fixed shapes, so it is captured once (stream capture of the very same C-ABI
 launches) and replayed with one launch; inputs are copied into the captured input buffers, the output is copied out.
+Shapes of at most SMALL_ROWS rows (the ragged rollout batches of an MCTS search: 1 .. 16 rows) have their own, larger budget: a small
+forward runs at its launch floor (~620 dependent kernels), so there every row of padding and every eager forward is pure loss, while a
+small graph's private pool is small.
 
 Not a tracing compiler: nothing is rewritten or fused, the graph is the eager launch sequence.  The first calls of a shape run
 eagerly (they also perform the one-time `hipFuncSetAttribute` calls), the third is captured; a module stops capturing new
@@ -22,7 +25,10 @@ import torch
 
 ENABLED = os.environ.get('DTS_GRAPHS', '1') != '0'
 MAX_GRAPHS = 4                      # per module; each holds the activations of one forward in its private pool
-MAX_CAPTURES = 8                    # per module: a caller with ever-changing batch sizes (MCTS rollouts) stays eager after that
+MAX_CAPTURES = 8                    # per module: a caller with ever-changing batch sizes stays eager after that
+SMALL_ROWS = 16                     # shapes with at most this many rows count against the SMALL budget instead
+MAX_GRAPHS_SMALL = 16
+MAX_CAPTURES_SMALL = 24
 SIGHTINGS = 3                       # a shape is captured on its third call
 
 
@@ -37,6 +43,7 @@ class GraphCache:
         self.graphs = OrderedDict()
         self.replays = 0
         self.captures = 0
+        self.captures_by_class = [0, 0]  # [large, small]
         self.eager = 0                  # forwards launched kernel by kernel (first sightings of a shape, shapes beyond MAX_CAPTURES, graphs off)
         self.fallback = None            # why capturing stopped (only with DTS_GRAPHS_STRICT=0)
 
@@ -56,7 +63,8 @@ class GraphCache:
         ent = self.graphs.get(key)
         if ent is None:
             self.seen[key] = self.seen.get(key, 0) + 1
-            if self.seen[key] < SIGHTINGS or self.captures >= MAX_CAPTURES:
+            small = self._small(key)
+            if self.seen[key] < SIGHTINGS or self.captures_by_class[small] >= (MAX_CAPTURES_SMALL if small else MAX_CAPTURES):
                 self.eager += 1
                 return self.fn(*inputs)
             ent = self._capture(key, inputs)
@@ -70,6 +78,11 @@ class GraphCache:
         graph.replay()
         self.replays += 1
         return static_out.clone()
+
+    @staticmethod
+    def _small(key):
+        rows = max((k[0][0] for k in key if k is not None and len(k[0]) > 0), default=0)
+        return int(0 < rows <= SMALL_ROWS)
 
     def _capture(self, key, inputs):
         static_in = [None if t is None else t.clone() for t in inputs]
@@ -96,8 +109,11 @@ class GraphCache:
             if gc_was_on:
                 gc.enable()
         self.captures += 1
-        while len(self.graphs) >= MAX_GRAPHS:
-            self.graphs.popitem(last=False)
+        small = self._small(key)
+        self.captures_by_class[small] += 1
+        mine = [k for k in self.graphs if self._small(k) == small]           # insertion order: oldest first
+        while len(mine) >= (MAX_GRAPHS_SMALL if small else MAX_GRAPHS):
+            del self.graphs[mine.pop(0)]
         self.graphs[key] = (graph, static_in, static_out)
         return self.graphs[key]
 

@@ -304,7 +304,9 @@ class _Node:
         self.x, self.children, self.reward, self.visit = x, [], 0, visit
 
 
-MCTS_PAD_ROLLOUTS = os.environ.get('DTS_MCTS_PAD', '1') != '0'      # batch the ragged rollouts in multiples of 4 rows (graph replay)
+# granularity the ragged rollout batches are padded to (copies of row 0, not counted as evaluations).  1 = no padding: every batch size
+# 1 .. 16 gets its own captured HIP graph (graphs.py SMALL budget); 4 = the former rule (four batch shapes, up to 3 wasted rows per forward)
+MCTS_PAD_ROLLOUTS = max(1, int(os.environ.get('DTS_MCTS_PAD', '1')))
 
 
 def _mcts(L: _Loop, t_steps, x_next, labels, p, pre):
@@ -379,16 +381,16 @@ def _mcts(L: _Loop, t_steps, x_next, labels, p, pre):
                         act = [q for q in mine if starts[q][1] <= j]
                         xa = torch.cat([cur[q] for q in act], dim=0)
                         la = None if lb is None else torch.cat([lb[starts[q][2]:starts[q][2] + 1] for q in act], dim=0).contiguous()
-                        # the number of live rollouts changes from step to step (1 .. 16): rounded up to a multiple of 4 with copies of
-                        # row 0, so the denoiser sees four batch shapes and replays their captured HIP graphs instead of launching
-                        # ~500 kernels one by one from the host for every odd size.  Rows are independent, so the live rows do not
-                        # depend on the padding VALUES; they can depend on the padded batch SIZE in the last bits, because the conv
-                        # launchers choose the split-K factor / launch form from the row count (another fixed f32 summation order --
-                        # as is every batch size against the reference's batch-1 rollouts, edm/main.py:640-660).  The f32 parity mode,
-                        # the mode the others are measured against, runs its rollouts unpadded; padding rows are not counted as evaluations.
+                        # the number of live rollouts changes from step to step (1 .. 16).  Every size replays its own captured HIP graph
+                        # (graphs.py keeps up to 16 small shapes per module) instead of launching ~600 kernels one by one from the host.
+                        # DTS_MCTS_PAD=4 restores the former rule -- sizes rounded up to a multiple of 4 with copies of row 0, four shapes --
+                        # which cost up to 3 wasted rows per forward at ~0.5 ms per row (profiles/r05_experiments.txt item 13).  Rows are
+                        # independent of each other's VALUES; they can depend on the batch SIZE in the last bits, because the conv launchers
+                        # choose the split-K factor / launch form from the row count (another fixed f32 summation order -- as is every
+                        # batch size against the reference's batch-1 rollouts, edm/main.py:640-660).  Padding rows are not counted as evaluations.
                         ka = len(act)
-                        pad = MCTS_PAD_ROLLOUTS and ka <= 16 and getattr(L.net, 'dtype', None) != torch.float32
-                        kp = -(-ka // 4) * 4 if pad else ka
+                        g_ = MCTS_PAD_ROLLOUTS if (ka <= 16 and getattr(L.net, 'dtype', None) != torch.float32) else 1
+                        kp = -(-ka // g_) * g_
                         if kp > ka:
                             xa = torch.cat([xa, xa[:1].expand(kp - ka, *xa.shape[1:])], dim=0)
                             if la is not None:
