@@ -328,6 +328,10 @@ def test_config3_free_running_search_split_precision_equals_f32_and_16bit_is_rep
     # those -- the f32 mode's own pick moved there when its strip-moment summation order was changed in round 5.  Measured 72/72; a
     # difference is accepted only at such a decision, and the final image must agree either way.)
     assert (r3['same_selections'] == '72/72' or r3.get('first_difference_is_below_fp32_noise')) and r3['max_abs_x_final_vs_f32'] < 1e-3, r3
+    if 'reference_run' in rec:       # the same searches against the REFERENCE's own run (tests/golden/config3_golden.npz; seed chosen for decidable margins)
+        for r_ in (rec['reference_run']['f32'], r3['vs_reference_run']):
+            assert (r_['first_differing_selection'] is None and r_['max_abs_x_final'] < 1e-3 and r_['png_pixels_differing'] <= 60) \
+                or r_.get('first_difference_is_below_fp32_noise'), r_
     for name in ('f16', 'bf16'):
         r = rec[name]
         assert np.isfinite(r['max_abs_x_final_vs_f32']) and abs(r['final_score'] / rec['f32_final_score'] - 1) < 0.02, (name, r)
