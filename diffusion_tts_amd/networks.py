@@ -238,36 +238,6 @@ class EDMPrecond:
     def _device_forward(self, x, sigma, class_labels):
         """The fixed-shape device part of the forward (all inputs already on the GPU): what graphs.GraphCache captures."""
         xin, coef = ops.edm_precond_in(x, sigma, self.sigma_data)
-        nbr = int(os.environ.get('DTS_ROW_BRANCHES', '1'))              # EXPERIMENT: row chunks as concurrent, phase-shifted chains
-        n = x.shape[0]
-        if nbr > 1 and n % nbr == 0 and n // nbr >= 8:
-            cur = torch.cuda.current_stream()
-            if not hasattr(self, '_side'):
-                self._side = [torch.cuda.Stream(device=self.device) for _ in range(nbr - 1)]
-            fork = torch.cuda.Event()
-            fork.record(cur)
-            m = n // nbr
-            cn = coef[:, 3].contiguous()
-            outs = [None] * nbr
-            joins = []
-            delay = int(os.environ.get('DTS_BRANCH_DELAY', '0'))
-            for b_ in range(1, nbr):
-                st = self._side[b_ - 1]
-                st.wait_event(fork)
-                with torch.cuda.stream(st):
-                    if delay > 0:
-                        torch.cuda._sleep(delay * b_)
-                    lab = None if class_labels is None else class_labels[b_ * m:(b_ + 1) * m].contiguous()
-                    outs[b_] = self.unet(xin[b_ * m:(b_ + 1) * m].contiguous(), cn[b_ * m:(b_ + 1) * m].contiguous(), lab)
-                    j_ = torch.cuda.Event()
-                    j_.record(st)
-                    joins.append(j_)
-            lab = None if class_labels is None else class_labels[:m].contiguous()
-            outs[0] = self.unet(xin[:m].contiguous(), cn[:m].contiguous(), lab)
-            for j_ in joins:
-                cur.wait_event(j_)
-            F = torch.cat(outs, dim=0)
-            return ops.edm_precond_out(x, F, coef)
         F = self.unet(xin, coef[:, 3].contiguous(), class_labels)
         return ops.edm_precond_out(x, F, coef)
 
