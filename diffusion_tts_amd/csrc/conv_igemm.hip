@@ -1749,7 +1749,7 @@ bool conv_pp_eligible(int dtype, int ksize, int cout, int c1, int c2, int n, int
 // Measured (tools/conv_bench.py --variants, profiles/r02_conv_variants.txt): 3x3 layers +3..11 %, 1x1 layers -10..15 % (their 6-12 K
 // tiles do not amortise the exposed prologue/epilogue of a one-block-per-CU kernel): 3x3 only.  With a residual input the epilogue's
 // residual fetch is exposed in the ping-pong kernel (no early fetch): short-K layers (cin < 384) then lose 2-3 % to the 4-wave kernel.
-int conv_pick_pp(bool f32, const ConvP& p) {
+int conv_pick_pp(bool f32, const ConvP& p, bool x3 = false) {
   const int variant = dts_knob_get(DTS_KNOB_CONV_VARIANT);      // 1 = ping-pong wherever it applies, 0 = never, unset = by shape
   if (f32 || variant == 0 || dts_knob_get(DTS_KNOB_CONV_TILE) > 0) return 0;
   // 3x3 only.  The kernel's 1x1 form (TAPS = 1) was 5-20 % slower than the 4-wave kernel on every 1x1 layer, and with more than one
@@ -1773,7 +1773,10 @@ int conv_pick_pp(bool f32, const ConvP& p) {
   // runs 38 us against 31 on the implicit-GEMM kernel, whose 128 x 128 tiles give twice the blocks: -4 % on that workload's step.  Keyed on
   // the image size: the classifier's 16x16 layers are the same GEMM at 64 rows, but routed the same way they cost the ADM headline 0.5 %
   // (their neighbours keep the operands of the ping-pong form warm; profiles/r03_small_batch_experiments.txt item 9c).
-  const bool half_round_128 = mt == 4 && blocks_pp > 64 && blocks_pp <= 128 && p.wout >= 32 && p.cout <= 256 && dts_knob_get(DTS_KNOB_CONV_HALF_ROUND) != 0;
+  // NOT in the split-precision mode: with three MFMAs per staged K step the ping-pong form's half round (+ its K split) beats the
+  // 128 x 128 implicit-GEMM grid there -- DDPM++-32 rejection step 9.07 -> 8.82 ms, same box, alternating (profiles/r05_experiments.txt item 16).
+  const int hr_knob = dts_knob_get(DTS_KNOB_CONV_HALF_ROUND);     // unset: by mode; 1 / 0 force the rule on / off (A/B aid)
+  const bool half_round_128 = mt == 4 && blocks_pp > 64 && blocks_pp <= 128 && p.wout >= 32 && p.cout <= 256 && (x3 ? hr_knob == 1 : hr_knob != 0);
   const bool auto_pp = p.taps == 9 && !short_small && !half_round_128;     // (round 2 excluded residual layers with cin < 384: since the COMPUTE-side trims of round 3 the ping-pong kernel wins there too, profiles/r03_conv_variants.txt)
   return (auto_pp && blocks_pp >= 64) ? mt : 0;
 }
@@ -1786,7 +1789,7 @@ int conv_dispatch(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes,
   // slices now come two at a time: 204-220 VGPRs, no scratch).  DTS_F32_TILE192=0 restores the smaller tile (A/B aid).
   static const bool f32_192 = !(getenv("DTS_F32_TILE192") && atoi(getenv("DTS_F32_TILE192")) == 0);
   if (std::is_same<T, float>::value && tile == 192 && !f32_192) tile = (p.cout % 128 == 0) ? 128 : 64;
-  const int pp = conv_pick_pp(std::is_same<T, float>::value, p);
+  const int pp = conv_pick_pp(std::is_same<T, float>::value, p, !std::is_same<T, OT>::value);
   if constexpr (!std::is_same<T, OT>::value) {       // split-precision mode: the two shipped ping-pong forms and the implicit-GEMM forms, no knob variants
     if (pp == 6) return launch_conv_pp<T, 9, 0, false, 6, OT>(p, st, ws, ws_bytes, call);
     if (pp == 4) return launch_conv_pp<T, 9, 0, false, 4, OT>(p, st, ws, ws_bytes, call);
@@ -1858,7 +1861,7 @@ extern "C" int dts_conv_kernel(const dts_conv_args* a) {
   if ((long long)a->n * a->hin * a->win * (a->up ? 4 : 1) >= (1ll << 30)) return -1;
   ConvP p;
   conv_shape_from_args(a, p);
-  return conv_pick_pp(a->dtype == DTS_F32, p);
+  return conv_pick_pp(a->dtype == DTS_F32, p, a->dtype == DTS_F16X3);
 }
 
 extern "C" int dts_conv_fuses_gn(const dts_conv_args* a) {
