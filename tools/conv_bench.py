@@ -70,12 +70,16 @@ def main():
 
 
 def ab(a):
-    dt = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[a.dtype]
+    x3 = a.dtype == 'f16x3'          # split precision: f32 tensors, the conv reads a split image and packed (hi | lo) weights
+    dt = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32, 'f16x3': torch.float32}[a.dtype]
     variants = [dict((kv.split('=')[0], int(kv.split('=')[1])) for kv in v.split(',')) for v in a.variants]
     tot = [[0.0, 0.0] for _ in variants]
     for name, r, cin, cout, k in SHAPES:
         x = torch.randn(a.n, r, r, cin, device='cuda').to(dt)
         w = (torch.randn(cout, k, k, cin, device='cuda') / (cin * k * k) ** 0.5).to(dt)
+        if x3:
+            w = ops.pack_conv_weight(torch.randn(cout, cin, k, k, device='cuda') / (cin * k * k) ** 0.5, ops.F16X3)
+            x = ops.SplitAct(ops.split3_f16(x), cin)
         b = torch.randn(cout, device='cuda')
         ro = 2 * r if a.up else r
         res = None if (a.no_res or a.up) else torch.randn(a.n, r, r, cout, device='cuda').to(dt)
