@@ -16,6 +16,7 @@ A refused capture is an ERROR (the product must not run 3-5x slower at small bat
 not report eager-launch numbers under the graph-replay name); `DTS_GRAPHS_STRICT=0` opts into the eager fallback explicitly, and then
 `GraphCache.fallback` records why.  `path_report()` says which path a module's forwards took (main.py prints it)."""
 import gc
+import math
 import os
 import warnings
 import weakref
@@ -81,8 +82,11 @@ class GraphCache:
 
     @staticmethod
     def _small(key):
-        rows = max((k[0][0] for k in key if k is not None and len(k[0]) > 0), default=0)
-        return int(0 < rows <= SMALL_ROWS)
+        # at most SMALL_ROWS rows of at most 3 x 128 x 128 elements each: a graph's private pool stays a few hundred MB even for the widest net
+        shapes = [k[0] for k in key if k is not None and len(k[0]) > 0]
+        rows = max((sh[0] for sh in shapes), default=0)
+        per_row = max((math.prod(sh[1:]) for sh in shapes), default=0)
+        return int(0 < rows <= SMALL_ROWS and per_row <= 3 * 128 * 128)
 
     def _capture(self, key, inputs):
         static_in = [None if t is None else t.clone() for t in inputs]
