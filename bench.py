@@ -46,6 +46,27 @@ def torch_dtype(name):
 GFLOP_PER_EVAL = {'adm64': 219.33, 'ddpmpp32': 42.38}             # BASELINE.md section 2 / SURVEY.md 8(d)
 CLS_GFLOP_PER_IMG = 38.16
 # written by tools/final_run.sh at HEAD: tools/pmc_traffic.py from the rocprofv3 --pmc passes, tools/rocprof_dominant.py from the --kernel-trace --stats pass
+def csrc_digest():
+    """sha256 over the kernel sources the library is built from (csrc/*.hip, dts_common.h, include/dts.h): the static profile files quoted
+    in the line carry the digest of the tree they were collected from (tools/collect_profiles.sh), so a kernel edit without re-running the
+    profile passes shows up as `stale: true` instead of riding along silently."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, 'diffusion_tts_amd', 'csrc', '*.hip'))) + [os.path.join(ROOT, 'diffusion_tts_amd', 'csrc', 'dts_common.h'),
+                                                                                          os.path.join(ROOT, 'include', 'dts.h')]
+    for f_ in files:
+        with open(f_, 'rb') as fh:
+            h.update(os.path.basename(f_).encode() + b'\0' + fh.read())
+    return h.hexdigest()[:16]
+
+
+def _stale(doc):
+    """True / False when the profile records the kernel-source digest it was collected from, None when it predates the field"""
+    d = doc.get('csrc_sha256')
+    return None if d is None else d != csrc_digest()
+
+
 TRAFFIC_PROFILE = {'f16x3': 'profiles/r05_hbm_traffic_pmc_f16x3.json', 'bf16': 'profiles/r05_hbm_traffic_pmc_bf16.json'}
 ROCPROF_PROFILE = {'f16x3': 'profiles/r05_rocprof_dominant_f16x3.json', 'bf16': 'profiles/r05_rocprof_dominant_bf16.json'}
 
@@ -261,7 +282,7 @@ def conv_roofline(a, run_once, reps, dtype_name, value_per_gpu, gflop_per_eval, 
     kernels = {k_: dict(launches=v['launches'], tflops=round(v['gflop'] / max(v['ms'], 1e-9), 1), avg_launch_us=round(v['ms'] * 1e3 / v['launches'], 2),
                         alg_mb_per_launch=round(v['alg_mb'] / v['launches'], 1)) for k_, v in per_kernel.items()}
     dom_family = max(per_kernel, key=lambda k_: per_kernel[k_]['ms'])
-    traffic, tsrc, rp = None, None, None
+    traffic, tsrc, rp, traffic_stale = None, None, None, None
     headline_shape = a.workload == 'adm64_eps_greedy' and a.candidates == 64 and a.gpus == 1
     try:        # HBM bytes per launch of the dominant kernel: a STATIC figure from committed rocprofv3 --pmc passes of this very
         # command in this dtype (counters cannot be collected from inside the process), valid for the default workload only
@@ -269,6 +290,7 @@ def conv_roofline(a, run_once, reps, dtype_name, value_per_gpu, gflop_per_eval, 
             with open(os.path.join(ROOT, TRAFFIC_PROFILE[dtype_name])) as f:
                 doc = json.load(f)
             traffic = round(doc['kernels_by_family'][dom_family]['hbm_bytes_per_launch'])
+            traffic_stale = _stale(doc)
             tsrc = (f'static, from {TRAFFIC_PROFILE[dtype_name]} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of this command, collected at commit '
                     f'{doc.get("collected_at_commit", "unknown")}; counters cannot be read from inside the process, so NOT measured in this run)')
     except Exception:
@@ -297,9 +319,10 @@ def conv_roofline(a, run_once, reps, dtype_name, value_per_gpu, gflop_per_eval, 
         rus = float(rp['avg_launch_us'])
         out_extra['rocprof_avg_launch_us'] = round(rus, 2)
         out_extra['rocprof_frac'] = round(d['gflop'] / d['launches'] / (rus * 1e-3) / peak, 4)      # GFLOP / ms = TFLOP/s
+        out_extra['rocprof_stale'] = _stale(rp)
         out_extra['rocprof_source'] = f"static, {ROCPROF_PROFILE[dtype_name]} (rocprofv3 --kernel-trace --stats of this command at commit {rp.get('collected_at_commit', 'unknown')}, {rp.get('calls')} calls)"
     return {'bound': 'mfma', 'achieved': round(dach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(dach / peak, 4), **out_extra,
-            'traffic': traffic, 'traffic_source': tsrc, 'kernel': dom, 'launches': d['launches'],
+            'traffic': traffic, 'traffic_source': tsrc, 'traffic_stale': traffic_stale, 'kernel': dom, 'launches': d['launches'],
             'avg_launch_us': round(d['ms'] * 1e3 / d['launches'], 2), 'avg_launch_gflop': round(d['gflop'] / d['launches'], 3),
             'alg_mb_per_launch': round(d['alg_mb'] / d['launches'], 1), 'ms_per_step': round(d['ms'] / reps, 2),
             'all_conv': {'achieved': round(ach, 1), 'frac': round(ach / peak, 4), 'launches': len(rec),

@@ -70,7 +70,7 @@ SIGNATURES = {
 OTHER = {'dts_version': ([], _i), 'dts_conv_fuses_gn': ([C.POINTER(ConvArgs)], _i), 'dts_conv_kernel': ([C.POINTER(ConvArgs)], _i), 'dts_set_tuning': ([_i, _i], _i), 'dts_get_tuning': ([_i], _i), 'dts_last_error': ([], C.c_char_p), 'dts_gn_ws_floats': ([_i, _i], _i64)}
 
 _lib = None
-ABI_VERSION = 109              # include/dts.h DTS_ABI_VERSION this binding was written against (ConvArgs = 184 bytes)
+ABI_VERSION = 110              # include/dts.h DTS_ABI_VERSION this binding was written against (ConvArgs = 184 bytes)
 
 
 def load():

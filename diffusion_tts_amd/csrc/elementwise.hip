@@ -457,11 +457,15 @@ __global__ __launch_bounds__(256) void candidate_noise_sd_kernel(const T* __rest
   __syncthreads();
   T nrm_t;
   st1<T>(&nrm_t, sqrtf((red[0] + red[1]) + (red[2] + red[3])));
-  const float nrm = ld1<T>(&nrm_t), sc = scale[cn];
+  // `to_add * rand * lambda * sqrt(numel)` (:1379) is ((to_add * rand) * lambda) * sqrt: three tensor-by-scalar products, each rounded to T
+  // (torch multiplies in f32 with the scalar cast to f32 and rounds the result to the tensor's type)
+  const float nrm = ld1<T>(&nrm_t), s0 = scale[3 * cn], s1 = scale[3 * cn + 1], s2 = scale[3 * cn + 2];
   for (int i = threadIdx.x; i < count; i += blockDim.x) {
     T a, b, c;
     st1<T>(&a, ld1<T>(ur + i) / nrm);                         // to_add / torch.norm(to_add)
-    st1<T>(&b, ld1<T>(&a) * sc);                              // * (rand * lambda * sqrt(numel)): python scalar, f32 math
+    st1<T>(&b, ld1<T>(&a) * s0);                              // * torch.rand(1).item()
+    st1<T>(&a, ld1<T>(&b) * s1);                              // * params['lambda']
+    st1<T>(&b, ld1<T>(&a) * s2);                              // * np.sqrt(numel)
     st1<T>(&c, ld1<T>(pivot + i) + ld1<T>(&b));               // pivot + ...
     out[i] = c;
   }

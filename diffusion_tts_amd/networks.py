@@ -242,8 +242,19 @@ class EDMPrecond:
         return ops.edm_precond_out(x, F, coef)
 
     @torch.no_grad()
-    def __call__(self, x, sigma, class_labels=None):
-        """EDMPrecond.forward (networks.py:654-668)."""
+    def __call__(self, x, sigma, class_labels=None, force_fp32=False, **model_kwargs):
+        """EDMPrecond.forward (networks.py:654-668), same signature.  `force_fp32` only matters to the reference when the checkpoint says
+        use_fp16 and the device is a GPU (networks.py:658); here the compute mode is fixed at construction (`dtype`), and every mode but
+        float16 already computes at least at the reference's fp32 precision, so the flag is honoured where it can be (a float16 network
+        refuses it instead of silently answering in half precision).  `model_kwargs` go to the U-Net in the reference (`augment_labels`
+        is the only one its models take, None at inference): anything else is an error, as it would be there."""
+        if force_fp32 and self.dtype == torch.float16:
+            raise ValueError('force_fp32=True: this network was built with dtype=float16; build it with dtype=ops.F16X3 (default) or float32')
+        aug = model_kwargs.pop('augment_labels', None)
+        if aug is not None:
+            raise NotImplementedError('augment_labels: training-time augmentation conditioning is outside the sampling path (networks.py:330-331)')
+        if model_kwargs:
+            raise TypeError(f'unexpected keyword arguments {sorted(model_kwargs)} (the reference U-Nets would raise too)')
         x = x.to(self.device, torch.float64).contiguous()
         n = x.shape[0]
         sigma = torch.as_tensor(sigma).to(self.device, torch.float64).reshape(-1).contiguous()

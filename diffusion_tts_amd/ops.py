@@ -601,9 +601,12 @@ def candidate_noise(pivot, g, mode, scale):
 
 
 def candidate_noise_sd(pivot, u, mode, scale):
-    """pivot [1,C,H,W], u [N,1,C,H,W] (same dtype), mode int32 [N], scale f32 [N] -> candidates [N,1,C,H,W]: the SD backend's
-    eps-greedy / zero-order builder (pipeline_stable_diffusion.py:1371-1379) in the latents' dtype."""
+    """pivot [1,C,H,W], u [N,1,C,H,W] (same dtype), mode int32 [N], scale f32 [N,3] = (rand, lambda, sqrt(numel)) per candidate ->
+    candidates [N,1,C,H,W]: the SD backend's eps-greedy / zero-order builder (pipeline_stable_diffusion.py:1371-1379) in the latents' dtype,
+    the three tensor-by-scalar products rounded one by one like the reference's."""
     n = u.shape[0]
+    if tuple(scale.shape) != (n, 3):
+        raise ValueError(f'candidate_noise_sd: scale must be [{n}, 3] (rand, lambda, sqrt(numel)), got {tuple(scale.shape)}')
     out = torch.empty_like(u)
     _call('dts_candidate_noise_sd', _ptr(pivot, 'pivot'), _ptr(u, 'u', pivot.dtype), _ptr(mode, 'mode', torch.int32),
           _ptr(scale, 'scale', torch.float32), _ptr(out), dt_code(pivot.dtype), n, pivot.numel())

@@ -87,6 +87,7 @@ class _Loop:
         self.record_noises, self.best_noises = False, {}
         self.reuse_winner = False
         self.forced = None                    # generate_image_grid(forced_selections=...)
+        self.chunk = None                     # generate_image_grid(candidate_chunk=...)
 
     def up(self, t, dtype=None):
         return t.to(self.dev, dtype).contiguous() if dtype is not None else t.to(self.dev).contiguous()
@@ -262,8 +263,21 @@ def _eps_greedy(L: _Loop, t_steps, x_next, labels, p, pre):
             torch.cuda.current_stream(L.dev).wait_event(ready)
             g_l.record_stream(torch.cuda.current_stream(L.dev))
             cand = ops.candidate_noise(pivot, g_l, L.up(mode_t[lo:hi]), L.up(scale_t[lo:hi]))
-            x_cand, x0 = L.step(x_cur, t_cur, t_next, i, cand, lab_l, nb=nl * B)
-            loc = L.score(p.scorer, x0, lab_l).to(L.dev, torch.float32)
+            if L.chunk is None or L.chunk * B >= nl * B:
+                x_cand, x0 = L.step(x_cur, t_cur, t_next, i, cand, lab_l, nb=nl * B)
+                loc = L.score(p.scorer, x0, lab_l).to(L.dev, torch.float32)
+            else:
+                # candidate_chunk: this rank's candidates go through the denoiser and the scorer in sequential pieces of `chunk` candidates
+                # (n-major rows, so a piece is chunk * B consecutive rows) -- exactly the launches rank r of N / chunk ranks issues for
+                # its share, on one GPU
+                xs, locs = [], []
+                for a in range(0, nl * B, L.chunk * B):
+                    z = min(nl * B, a + L.chunk * B)
+                    lab_c = None if lab_l is None else lab_l[a:z].contiguous()
+                    xc_, x0_ = L.step(x_cur, t_cur, t_next, i, cand[a:z].contiguous(), lab_c, nb=z - a)
+                    xs.append(xc_.clone())
+                    locs.append(L.score(p.scorer, x0_, lab_c).to(L.dev, torch.float32).clone())
+                x_cand, loc = torch.cat(xs, dim=0), torch.cat(locs, dim=0)
             draws.prefetch()                                                           # host draws overlap the queued GPU work
             scores = L.shards.gather_rewards(loc, N, B).reshape(N, B).cpu()
             best = scores.argmax(dim=0)                                                # first max (:842)
@@ -306,7 +320,21 @@ class _Node:
 
 # granularity the ragged rollout batches are padded to (copies of row 0, not counted as evaluations).  1 = no padding: every batch size
 # 1 .. 16 gets its own captured HIP graph (graphs.py SMALL budget); 4 = the former rule (four batch shapes, up to 3 wasted rows per forward)
-MCTS_PAD_ROLLOUTS = max(1, int(os.environ.get('DTS_MCTS_PAD', '1')))
+# DTS_MCTS_PAD_ROWS sets it.  DTS_MCTS_PAD keeps the boolean meaning it had through round 4 ('1' = pad to multiples of four, '0' = no padding).
+def _mcts_pad_rows():
+    v = os.environ.get('DTS_MCTS_PAD_ROWS')
+    if v is None:
+        legacy = os.environ.get('DTS_MCTS_PAD')
+        return 4 if legacy is not None and legacy.strip() not in ('', '0') else 1
+    try:
+        return max(1, min(16, int(v)))
+    except ValueError:
+        import warnings
+        warnings.warn(f'DTS_MCTS_PAD_ROWS={v!r} is not an integer: rollout batches are not padded')
+        return 1
+
+
+MCTS_PAD_ROLLOUTS = _mcts_pad_rows()
 
 
 def _mcts(L: _Loop, t_steps, x_next, labels, p, pre):
@@ -383,7 +411,7 @@ def _mcts(L: _Loop, t_steps, x_next, labels, p, pre):
                         la = None if lb is None else torch.cat([lb[starts[q][2]:starts[q][2] + 1] for q in act], dim=0).contiguous()
                         # the number of live rollouts changes from step to step (1 .. 16).  Every size replays its own captured HIP graph
                         # (graphs.py keeps up to 16 small shapes per module) instead of launching ~600 kernels one by one from the host.
-                        # DTS_MCTS_PAD=4 restores the former rule -- sizes rounded up to a multiple of 4 with copies of row 0, four shapes --
+                        # DTS_MCTS_PAD_ROWS=4 restores the former rule -- sizes rounded up to a multiple of 4 with copies of row 0, four shapes --
                         # which cost up to 3 wasted rows per forward at ~0.5 ms per row (profiles/r05_experiments.txt item 13).  Rows are
                         # independent of each other's VALUES; they can depend on the batch SIZE in the last bits, because the conv launchers
                         # choose the split-K factor / launch form from the row count (another fixed f32 summation order -- as is every
@@ -438,7 +466,7 @@ def generate_image_grid(
     precomputed_noise: Optional[Dict[Any, torch.Tensor]] = None,
     *, scale_fn: Callable[[int, int, int], float] = builtin_scale, compute_dtype=ops.F16X3, verbose=True,
     reuse_winner: Optional[bool] = None, record_noises: bool = False, shard_candidates: bool = True,
-    forced_selections: Optional[Sequence[int]] = None,
+    forced_selections: Optional[Sequence[int]] = None, candidate_chunk: Optional[int] = None,
 ):
     """Same positional/keyword surface as edm/main.py:47-55.  Keyword-only extras: `scale_fn` (the hash-derived step
     table, edm/main.py:776), `compute_dtype` (default ops.F16X3: split precision, the reference's fp32 selections at a third of the 16-bit
@@ -446,7 +474,11 @@ def generate_image_grid(
     (keep the per-iteration winning noises for `dump_noise_trajectory`; costs one D2H copy per iteration), `forced_selections` (eps-greedy /
     zero-order, one image: decision d continues from candidate forced_selections[d] instead of its own argmax, which is still what
     `selected` records -- how a search is walked along ANOTHER run's trajectory so that every decision of the two stays comparable; the
-    parity tests follow the reference's recorded run this way).  Writes the PNG grid like the
+    parity tests follow the reference's recorded run this way; it must hold num_steps * K indices in [0, N), and in a sharded run every
+    rank must pass the same list: the override is applied after the reward all-gather, on every rank alike), `candidate_chunk` (eps-greedy /
+    zero-order: evaluate the candidates of an iteration in sequential pieces of that many candidates instead of one batch -- the kernels,
+    split-K factors and launch forms a rank of a sharded run uses for a share of that size, on one GPU; values are the batched run's up to
+    the f32 summation order those launch forms imply).  Writes the PNG grid like the
     reference when `dest_path` is not None and additionally returns a dict with the final state and the search trace."""
     device = torch.device(device)
     if device.type != 'cuda':
@@ -470,6 +502,13 @@ def generate_image_grid(
         if sampling_method not in (SamplingMethod.EPS_GREEDY, SamplingMethod.ZERO_ORDER) or latents.shape[0] != 1:
             raise ValueError('forced_selections: eps-greedy / zero-order search of one image only')
         L.forced = [int(v) for v in forced_selections]
+        if len(L.forced) != num_steps * p.K or any(not 0 <= v < p.N for v in L.forced):
+            raise ValueError(f'forced_selections: need num_steps * K = {num_steps * p.K} indices in [0, {p.N}), got {len(L.forced)} '
+                             f'(range {min(L.forced, default=None)} .. {max(L.forced, default=None)})')
+    if candidate_chunk is not None:
+        if sampling_method not in (SamplingMethod.EPS_GREEDY, SamplingMethod.ZERO_ORDER) or int(candidate_chunk) < 1:
+            raise ValueError('candidate_chunk: a positive candidate count, eps-greedy / zero-order search only')
+        L.chunk = int(candidate_chunk)
     x0 = (latents.to(torch.float64).cpu() * t_steps[0]).to(device).contiguous()       # edm/main.py:99
     labels = None if class_labels is None else class_labels.to(device, torch.float32).contiguous()
     evals0 = getattr(net, 'evals', 0)

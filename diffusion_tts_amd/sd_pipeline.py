@@ -360,11 +360,11 @@ class SDSearchPipeline:
                             if r < thr:
                                 draws.append(randn())
                                 mode.append(0)
-                                scale.append(0.0)
+                                scale.append((0.0, 0.0, 0.0))
                             else:
                                 draws.append(randn())
                                 mode.append(1)
-                                scale.append(torch.rand(1).item() * params['lambda'] * np.sqrt(shape[-1] * shape[-2] * shape[-3]))
+                                scale.append((torch.rand(1).item(), float(params['lambda']), float(np.sqrt(shape[-1] * shape[-2] * shape[-3]))))
                         for _ in range(N):
                             randn()                                            # dropped variance noise (:1410)
                         cands = ops.candidate_noise_sd(pivot_d, self._up(torch.stack(draws), dtype), torch.tensor(mode, dtype=torch.int32, device=dev),

@@ -42,10 +42,11 @@ enum dts_dtype { DTS_F32 = 0, DTS_BF16 = 1, DTS_F16 = 2,
                  DTS_F16X3 = 3 };
 enum dts_status { DTS_OK = 0, DTS_ERR_ARG = -1, DTS_ERR_LAUNCH = -2, DTS_ERR_UNSUPPORTED = -3 };
 
-#define DTS_ABI_VERSION 109        /* bumped with every change of a signature or of dts_conv_args (101: ev_start/ev_stop; 102: tuning knobs; 103: dts_cosine_rows; 104: dts_nchw_to_nhwc_pad,
+#define DTS_ABI_VERSION 110        /* bumped with every change of a signature or of dts_conv_args (101: ev_start/ev_stop; 102: tuning knobs; 103: dts_cosine_rows; 104: dts_nchw_to_nhwc_pad,
                                      105: dts_conv_args.gn_coef / gn_silu, dts_conv_fuses_gn;
                                      head dim 512 in dts_attention; 106: dts_conv_kernel, 128-cout ping-pong blocks; 107: dts_resample_u8, dts_lut_u8_f32; 108: DTS_F16X3, dts_conv_args.acc_scale, dts_split3_f16, dts_gn_apply_x3, dts_split2_f16, dts_attention_x3;
-                                     109: dts_candidate_noise_sd; the DTS_F16X3 operand images are 2*C wide, interleaved per 32 channels; dts_gn_apply_x3 raw_out) */
+                                     109: dts_candidate_noise_sd; the DTS_F16X3 operand images are 2*C wide, interleaved per 32 channels; dts_gn_apply_x3 raw_out;
+                                     110: dts_candidate_noise_sd takes the three scalars of the reference's product separately (scale [n][3])) */
 int dts_version(void);            /* == DTS_ABI_VERSION of the build; a binding must refuse any other value */
 const char* dts_last_error(void);
 /* Tuning knobs (measurement aid; a knob only selects between kernels / block orders / ring depths that give correct results -- the
@@ -226,7 +227,8 @@ int dts_candidate_noise(const double* pivot, const double* g, const int32_t* mod
                         double* cand, int nb, int b, int chw, dts_stream s);
 /* The SD backend's builder (sd/diffusers/.../pipeline_stable_diffusion.py:1371-1379), in the latents' storage type `dtype` with the
  * reference's roundings: u host-drawn normals [n][count]; mode[c] == 0: cand[c] = u[c] (fresh noise, :1375);
- * mode[c] == 1: cand[c] = pivot + (u[c] / ||u[c]||) * scale[c], scale = rand * lambda * sqrt(count) (:1377-1379).  pivot [count]. */
+ * mode[c] == 1: cand[c] = pivot + ((((u[c] / ||u[c]||) * scale[3c]) * scale[3c+1]) * scale[3c+2]), scale[3c..] = (rand, lambda, sqrt(count)) as f32:
+ * the reference's three tensor-by-scalar products, each rounded to `dtype` (:1377-1379).  pivot [count], scale [n][3]. */
 int dts_candidate_noise_sd(const void* pivot, const void* u, const int32_t* mode, const float* scale, void* cand, int dtype, int n,
                            int64_t count, dts_stream s);
 

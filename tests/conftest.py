@@ -53,3 +53,31 @@ def manifest_c3():
         pytest.skip('tests/golden/config3_manifest.json not generated')
     with open(p) as f:
         return json.load(f)
+
+
+@pytest.fixture(scope='session')
+def golden_c3_seed0():
+    """a second run of configs[2] by the reference, at a seed that was not scanned on the GPU first (make_golden_config3.py --seed 0 --prefix config3_seed0)"""
+    p = os.path.join(ROOT, 'tests', 'golden', 'config3_seed0_golden.npz')
+    if not os.path.exists(p):
+        pytest.skip('tests/golden/config3_seed0_golden.npz not generated')
+    return np.load(p)
+
+
+@pytest.fixture(scope='session')
+def manifest_c3_seed0():
+    p = os.path.join(ROOT, 'tests', 'golden', 'config3_seed0_manifest.json')
+    if not os.path.exists(p):
+        pytest.skip('tests/golden/config3_seed0_manifest.json not generated')
+    with open(p) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope='session')
+def golden_mcts_full():
+    """the reference's own MCTS search at full network size (tests/golden/make_golden_mcts_fullsize.py)"""
+    p = os.path.join(ROOT, 'tests', 'golden', 'mcts_fullsize_golden.npz')
+    if not os.path.exists(p):
+        pytest.skip('tests/golden/mcts_fullsize_golden.npz not generated')
+    with open(os.path.join(ROOT, 'tests', 'golden', 'mcts_fullsize_manifest.json')) as f:
+        return np.load(p), json.load(f)

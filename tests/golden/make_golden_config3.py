@@ -60,15 +60,42 @@ def main():
     cls.load_state_dict(csd, strict=True)
     cls_ck = dinit.checksum(csd)
     for ck, ref in ((adm_ck['checksum'], fman['adm_imagenet64']['checksum']), (cls_ck, fman['cls_imagenet64']['checksum'])):
-        assert ck == ref, (ck, ref)                                  # the very weights fullsize_golden.npz was made with
+        # the very weights fullsize_golden.npz was made with (the f64 sums depend on the thread count in their last digits)
+        assert ck['numel'] == ref['numel'] and all(abs(ck[k_] - ref[k_]) <= 1e-12 * abs(ref[k_]) for k_ in ('sum', 'abs_sum')), (ck, ref)
     inet = mg.ref_scorers.ImageNetScorer.__new__(mg.ref_scorers.ImageNetScorer)
     torch.nn.Module.__init__(inet)
     inet.model = cls
     lat = torch.from_numpy(full['eg64_latents'])
     lab = torch.eye(1000)[torch.from_numpy(full['eg64_label_idx']).long()]
     seen = []
+    carried = []                                                     # per decision: what the reference's loop itself carried on (edm/main.py:842-857)
+    prev = {}
+
+    def ref_locals():
+        f = sys._getframe(1)
+        while f is not None and f.f_code.co_name != 'generate_image_grid':
+            f = f.f_back
+        assert f is not None
+        return f.f_locals
+
+    def note_carried(loc):
+        """`new_pivot_noise` of the reference's frame is the noise its own `scores.argmax` picked at the PREVIOUS decision (:842-850); which
+        candidate that was is read off by comparing it, bit for bit, with the rows of that decision's `all_noises` (:800)."""
+        if 'cand' not in prev:
+            return
+        piv = loc['new_pivot_noise'].detach().double()
+        hits = [n for n in range(prev['cand'].shape[0]) if torch.equal(prev['cand'][n], piv[0])]
+        assert hits, 'the carried pivot is none of the previous candidates'
+        v = piv.reshape(-1)
+        carried.append(dict(index=hits[0], n_equal_rows=len(hits), sum=float(v.sum()), abs_sum=float(v.abs().sum()), head=v[:8].tolist(),
+                            sha256=__import__('hashlib').sha256(piv.numpy().tobytes()).hexdigest()))
 
     def scorer(images, labels, timesteps):                           # progress: one line per decision
+        loc = ref_locals()
+        note_carried(loc)
+        prev.clear()
+        if images.shape[0] > 1:
+            prev['cand'] = loc['all_noises'].detach().double().clone()
         s = inet(images, labels, timesteps)
         seen.append(s.detach().numpy().copy())
         if s.shape[0] > 1:
@@ -85,10 +112,19 @@ def main():
     rewards = np.stack(rew[:nd])
     srt = np.sort(rewards, axis=1)[:, ::-1]
     gaps = (srt[:, 0].astype(np.float64) - srt[:, 1].astype(np.float64)).tolist()
-    out = dict(rewards=rewards, selected=rewards.argmax(axis=1).astype(np.int64), final_score=rew[nd], image=png,
+    # `selected` is what THE REFERENCE'S LOOP carried on (the candidate whose noise became its next pivot), not a re-derivation from the rewards
+    assert len(carried) == nd, len(carried)
+    selected = np.array([c['index'] for c in carried], dtype=np.int64)
+    checks = dict(carried_pivot_matches_one_candidate=all(c['n_equal_rows'] == 1 for c in carried),
+                  carried_equals_argmax_of_recorded_rewards=bool(np.array_equal(selected, rewards.argmax(axis=1))))
+    print(checks, flush=True)
+    out = dict(rewards=rewards, selected=selected, final_score=rew[nd], image=png,
+               pivot_sum=np.array([c['sum'] for c in carried]), pivot_abs_sum=np.array([c['abs_sum'] for c in carried]),
+               pivot_head=np.array([c['head'] for c in carried]),
                last_D=lg.calls[-1][2].numpy(), last_x=lg.calls[-1][0].numpy(), sigmas=np.array(sorted({float(c[1][0]) for c in lg.calls}, reverse=True)))
     man = dict(params=params, num_steps=num_steps, seed=a.seed, net_rows=int(sum(c[0].shape[0] for c in lg.calls)), scorer_calls=len(sl.calls),
-               top2_gaps=gaps, selected=[int(v) for v in out['selected']], exact_ties=int(sum(g == 0.0 for g in gaps)),
+               top2_gaps=gaps, selected=[int(v) for v in out['selected']], pivot_sha256=[c['sha256'] for c in carried], checks=checks,
+               selected_source='the candidate whose noise the reference loop carried as new_pivot_noise (edm/main.py:846-857), matched bit for bit', exact_ties=int(sum(g == 0.0 for g in gaps)),
                min_nonzero_gap=min((g for g in gaps if g > 0), default=None), S=dict(S_churn=40, S_min=0.05, S_max=50, S_noise=1.003),
                latents='fullsize_golden.npz eg64_latents / eg64_label_idx', adm_imagenet64=adm_ck, cls_checksum=cls_ck,
                torch=torch.__version__, numpy=np.__version__, threads=a.threads, seconds=round(time.time() - t00, 1))

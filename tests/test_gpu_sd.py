@@ -55,3 +55,34 @@ def test_sd_search_matches_reference(sdg, method, dead):
     assert np.allclose(np.array(out.scores), g[f'{method}_scores'], atol=2e-5)
     assert np.allclose(out.images.float().cpu().numpy(), g[f'{method}_image'], atol=2e-5)
     assert abs(float(score.item() if torch.is_tensor(score) else score) - meta['max_score']) < 2e-5
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.float32])
+def test_candidate_noise_sd_rounds_like_the_reference_expression(dtype):
+    """dts_candidate_noise_sd against the reference's own expression evaluated by torch on the CPU in the latents' dtype
+    (pipeline_stable_diffusion.py:1377-1379): `to_add / torch.norm(to_add)`, then `pivot + to_add * rand * lambda * np.sqrt(numel)` --
+    Python evaluates the products left to right, three tensor-by-scalar multiplies that each round in the tensor's type.  float16: bit for
+    bit (the norm is rounded to f16, which absorbs the summation order of its f32 accumulation); float32: within one ulp of the norm."""
+    from diffusion_tts_amd import ops
+    g = torch.Generator().manual_seed(3)
+    n, shape = 6, (1, 4, 64, 64)
+    pivot = torch.randn(shape, generator=g).to(dtype)
+    u = torch.randn((n,) + shape, generator=g).to(dtype)
+    mode = torch.tensor([1, 0, 1, 1, 0, 1], dtype=torch.int32)
+    rands = torch.rand(n, generator=g).tolist()
+    lam, root = 0.15, float(np.sqrt(shape[-1] * shape[-2] * shape[-3]))
+    want = []
+    for c in range(n):
+        if mode[c] == 0:
+            want.append(u[c])
+        else:
+            to_add = u[c] / torch.norm(u[c])
+            want.append(pivot + to_add * rands[c] * lam * root)
+    want = torch.stack(want)
+    scale = torch.tensor([[r, lam, root] if m_ else [0.0, 0.0, 0.0] for r, m_ in zip(rands, mode.tolist())], dtype=torch.float32)
+    got = ops.candidate_noise_sd(pivot.to(DEV), u.to(DEV), mode.to(DEV), scale.to(DEV)).cpu()
+    if dtype == torch.float16:
+        assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+    else:
+        assert float((got - want).abs().max()) <= 2 ** -22 * float(want.abs().max())
+        assert torch.equal(got[1], want[1]) and torch.equal(got[4], want[4])

@@ -18,6 +18,7 @@ for dt in f16x3 bf16; do
 python - $O/final_hbm_traffic_pmc_$dt.json profiles/${RD}_hbm_traffic_pmc_$dt.json $HEAD $dt <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1])); d['collected_at_commit'] = sys.argv[3]; d['dtype'] = sys.argv[4]      # the tree the counters were collected from (bench.py quotes it)
+sys.path.insert(0, '.'); import bench; d['csrc_sha256'] = bench.csrc_digest()      # ... and the digest of its kernel sources: bench.py flags the figure as stale when they change
 d['command'] = d['command'].replace('bench.py', 'bench.py --dtype ' + sys.argv[4])
 json.dump(d, open(sys.argv[2], 'w'))
 PY

@@ -7,6 +7,7 @@ JSON bench.py quotes beside its in-process figure (roofline.rocprof_avg_launch_u
 The kernel family is the one bench.py names `conv_pp_kernel` (the 192-cout ping-pong / halo form of the dtype's instantiation); recomputing
 avg_launch_gflop / avg_launch_us / peak from this file and the bench line gives the line's rocprof_frac."""
 import csv
+import os
 import json
 import sys
 
@@ -17,6 +18,12 @@ PAT = {'bf16': 'conv_pp_kernel<bf16_t, 9, 0, false, 6, bf16_t>', 'f16': 'conv_pp
 def short(name):
     import re
     return re.sub(r'\(ConvP\)$|\(AttP\)$', '', name.replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', ''))
+
+
+def _digest():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return bench.csrc_digest()
 
 
 def main():
@@ -30,7 +37,7 @@ def main():
     r = dom[0]
     doc = {'kernel_family': 'conv_pp_kernel', 'kernel': short(r['Name']), 'dtype': dtype,
            'calls': int(r['Calls']), 'avg_launch_us': round(float(r['AverageNs']) / 1e3, 3), 'share_of_kernel_time': round(float(r['TotalDurationNs']) / tot, 4),
-           'collected_at_commit': commit,
+           'collected_at_commit': commit, 'csrc_sha256': _digest(),
            'command': 'rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --dtype %s --no-cpu-baseline --no-kernel-timing --no-e2e --no-parity --no-subrecords' % dtype,
            'top_kernels': [{'name': short(x['Name'])[:90], 'calls': int(x['Calls']),
                             'avg_us': round(float(x['AverageNs']) / 1e3, 2), 'pct': float(x['Percentage'])} for x in rows[:12]]}
