@@ -710,6 +710,39 @@ def free_running_vs_f32(job, nets):
     return out
 
 
+def sharded_forms_vs_reference(job, net, scorer, dtype_name, chunk=8):
+    """The launch forms of a SHARDED search (BASELINE configs[2]: "candidates sharded 8 x") against the reference's own run: at 8 candidates
+    per rank every convolution picks other split-K factors / kernel forms than at 64 (another fixed f32 summation order).
+    generate_image_grid(candidate_chunk=8) issues exactly the launches rank r of 8 issues for its share, eight times per iteration, walked
+    along the reference's recorded selections so that all 72 decisions see the reference's candidates: reward errors, the build's own
+    argmax against the reference's wherever the reference's top-2 gap exceeds 4x the error there, final state and PNG."""
+    import numpy as np
+    import torch
+    from diffusion_tts_amd.sampler import SamplingMethod, generate_image_grid
+    from diffusion_tts_amd.hashing import seed0_scale
+    gold = reference_run_golden()
+    if gold is None:
+        return None
+    g, gm, glat = gold
+    lab = torch.eye(1000)[torch.tensor([5])]
+    sel_ref = [int(v) for v in g['selected']]
+    r = generate_image_grid(net, None, torch.from_numpy(glat), lab, seed=int(gm['seed']), gridw=1, gridh=1, device=job.dev, num_steps=18, S_churn=40,
+                            S_min=0.05, S_max=50, S_noise=1.003, sampling_method=SamplingMethod.EPS_GREEDY,
+                            sampling_params=dict(scorer=scorer, N=64, K=4, lambda_param=0.15, eps=0.4), scale_fn=seed0_scale,
+                            compute_dtype=torch_dtype(dtype_name), reuse_winner=False, verbose=False, forced_selections=sel_ref, candidate_chunk=chunk)
+    rew = np.stack([w_.reshape(-1).numpy() for w_ in r['rewards']]).astype(np.float64)
+    own = [int(s_[0]) for s_ in r['selected']]
+    errs = np.abs(rew - g['rewards'].astype(np.float64)).max(axis=1)
+    gaps = gm['top2_gaps']
+    dec = [d for d in range(72) if gaps[d] > 0 and gaps[d] > 4 * errs[d]]
+    img = r['image'][0].permute(1, 2, 0).numpy()
+    return {'what': f'config 3 walked along the reference run\'s selections with the candidates evaluated in pieces of {chunk} (the kernels of one rank of {64 // chunk})',
+            'dtype': dtype_name, 'max_reward_err': float(f'{errs.max():.3e}'), 'own_argmax_equals_reference': f'{sum(int(a_ == b_) for a_, b_ in zip(own, sel_ref))}/72',
+            'decidable': f'{sum(int(own[d] == sel_ref[d]) for d in dec)}/{len(dec)} (reference top-2 gap > 4x the reward error there; {sum(1 for g_ in gaps if g_ == 0)} exact ties besides)',
+            'net_rows': int(r['net_rows']), 'max_abs_x_final': float(f'{float((r["x"].double().cpu() - torch.from_numpy(g["last_D"]).double()).abs().max()):.3e}'),
+            'png_pixels_differing': int((img.astype(np.int32) != g['image'].astype(np.int32)).sum())}
+
+
 def _meets_vs_reference(rec):
     """north star against the reference's own run: every selection equal and the final image within 1e-3 (or the first difference at a decision
     the reference itself decided by less than the fp32 reward noise); True when the fixture is absent (then only the f32-mode comparison speaks)"""
@@ -939,11 +972,20 @@ def run_eps_greedy(a, job):
                                                 'max_reward_dev_while_states_equal': fr['max_reward_dev_while_states_equal'],
                                                 # the same search against THE REFERENCE'S OWN RUN of it (tests/golden/config3_golden.npz), when the fixture is in the tree
                                                 'vs_reference_run': fr.get('vs_reference_run'),
+                                                'fixture_seed': ('the search seed of this fixture (71) was picked on the GPU beforehand for wide top-2 margins (tools/seed_scan.py, '
+                                                                 'profiles/r05_seed_scan.txt: on most seeds some decision is decided by less than fp32 noise, i.e. a coin flip between '
+                                                                 'two correct fp32 summation orders); a second reference run at an UNSCANNED seed (0) is walked decision by decision in '
+                                                                 'tests/test_gpu_fullsize.py::test_config3_second_seed_walk_against_the_reference_run'),
                                                 # every selection equal, or the only differences sit where the reference's own top-2 gap is below fp32 noise
                                                 # (a decision no fp32 implementation reproduces: the f32 mode's own picks move there with its summation order)
                                                 'meets_north_star': bool((fr['same_selections'] == '72/72' or fr.get('first_difference_is_below_fp32_noise', False))
                                                                          and fr['max_abs_x_final_vs_f32'] <= 1e-3 and _meets_vs_reference(fr.get('vs_reference_run')))}
                                                if fr is not None else {'dtype': a.dtype, 'reference': 'this IS the f32 parity mode'})
+                try:
+                    extra['parity']['sharded_launch_forms'] = sharded_forms_vs_reference(job, nets[a.dtype][0], nets[a.dtype][1], a.dtype)
+                    log(f"sharded launch forms vs the reference run: {extra['parity']['sharded_launch_forms']}")
+                except Exception as e:          # (a record, not the measurement: say so instead of losing the line)
+                    extra['parity']['sharded_launch_forms'] = {'error': f'{type(e).__name__}: {e}'}
                 extra['parity_modes'] = parity_mode_records(a, job, nets)
             # the same timed region in the 16-bit THROUGHPUT modes (f16 is the reference's own CUDA dtype, networks.py:658): every throughput and
             # index-agreement figure then sits in ONE driver-run record.  They do not reproduce the reference's selections (parity.free_running_vs_f32).

@@ -310,8 +310,10 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
       tmax = vmax3(tmax, sacc[qt][2][3], sacc[qt][3][0]);
       tmax = vmax3(tmax, sacc[qt][3][1], sacc[qt][3][2]);
       tmax = vmax2(tmax, sacc[qt][3][3]);
-      tmax = vmax2(tmax, __shfl_xor(tmax, 16, 64));
-      tmax = vmax2(tmax, __shfl_xor(tmax, 32, 64));
+      {   // the other three lane groups' maxima in ONE crossbar round trip (three independent permutes) instead of two dependent ones
+        const float t16 = __shfl_xor(tmax, 16, 64), t32 = __shfl_xor(tmax, 32, 64), t48 = __shfl_xor(tmax, 48, 64);
+        tmax = vmax2(vmax3(tmax, t16, t32), t48);
+      }
       const float m_new = vmax2(m_run[qt], tmax);    // finite: every tile has >= 1 valid key
       const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * sc2);
       const float mb = m_new * sc2;
@@ -415,9 +417,12 @@ __global__ __launch_bounds__(256) void attention16_kernel(const AttP p) {
 //   P (f32 in [0,1] after exp2) * 2^14 -> ph, pl in registers;  O^T * 2^20 = Vh^T.ph + Vh^T.pl + Vl^T.ph,  l * 2^14 = ones.ph + ones.pl.
 // Structure, LDS rows (K' = Kh | Kl, V' = Vh | Vl: 256 B + 32 B pad), register prefetch, QT query tiles per wave and the transposed V
 // reads are attention16_kernel's; three MFMAs per fragment pair instead of one, and the fragment reads are what bounds it (QT = 2 halves them).
-template <int QT>
+template <int QT, int VAR = 7>
 __global__ __launch_bounds__(256) void attention_x3_kernel(const AttP p) {
   using T = f16_t;
+  // VAR (A/B aid, DTS_ATT_DB = 16 + VAR): bit 0 = K fragments of group j + 1 requested before the MFMAs of group j, bit 1 = both query tiles' maxima
+  // exchanged in one round, bit 2 = the first V^T fragments requested before the softmax
+  constexpr bool KPRE = (VAR & 1) != 0, SM2 = (VAR & 2) != 0;
   constexpr int D = 64, ES = 2, ROWB = 2 * D * ES + 32, CH = 2 * D / 8, KSTEPS = D / 32, DT = D / 16, NCH = (64 * CH) / 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sK = smem;
@@ -456,22 +461,41 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const AttP p) {
   }
   const int ntiles = (p.t + 63) / 64;
   uint4 pk[NCH], pv[NCH];
-  // chunk c of a K' / V' row: c < 8 -> hi plane chunk c, else lo plane chunk c - 8
+  // chunk c of a K' / V' row: c < 8 -> hi plane chunk c, else lo plane chunk c - 8.  Thread tid stages chunk c = tid & 15 of rows (tid >> 4) + 16 u.
+  // Addressing (round 6): buffer loads -- the block's descriptor (scalar registers), per-lane 32-bit byte offsets that never change, and the
+  // key tile as the instruction's SCALAR offset -- so a tile's eight loads cost no vector instruction at all; the former per-load 64-bit
+  // row * stride products, plane selects and row bound checks were ~100 of the loop's ~350 vector instructions per key tile (against 104
+  // MFMAs: the kernel is vector-issue bound).  A ragged last tile gives the rows past the end an out-of-range lane offset, which the
+  // buffer load turns into zeros (the scalar offset is not part of the range check, so the whole-tile form needs none).
+  static_assert(CH == 16 && NCH == 4, "tile staging layout");
+  typedef unsigned int att_u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rs_kv = __builtin_amdgcn_make_buffer_rsrc((void*)const_cast<char*>(base), 0, 0x7fff0000, 0x00020000);
+  uint32_t koff[NCH];
+  {
+    const int r = tid >> 4, c = tid & 15;
+#pragma unroll
+    for (int u = 0; u < NCH; ++u)
+      koff[u] = (uint32_t)((size_t)(r + 16 * u) * rowstride + (c < 8 ? 0 : LO) + (size_t)(c & 7) * 16 + (size_t)C * ES);
+  }
+  const uint32_t v_plane = (uint32_t)((size_t)C * ES);                                  // v sits one C-wide block behind k
+#define X3_LD(voff_, soff_) __builtin_bit_cast(uint4, (att_u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_kv, (int)(voff_), (int)(soff_), 0))
 #define X3_LOAD_TILE(key0_)                                                                      \
-  _Pragma("unroll") for (int u = 0; u < NCH; ++u) {                                               \
-    const int idx = tid + 256 * u, r = idx / CH, c = idx - r * CH;                                \
-    pk[u] = pv[u] = make_uint4(0, 0, 0, 0);                                                       \
-    if ((key0_) + r < p.t) {                                                                      \
-      const char* g = base + (size_t)((key0_) + r) * rowstride + (c < 8 ? 0 : LO) + (c & 7) * 16;  \
-      pk[u] = *reinterpret_cast<const uint4*>(g + (size_t)C * ES);                                \
-      pv[u] = *reinterpret_cast<const uint4*>(g + (size_t)2 * C * ES);                            \
+  {                                                                                               \
+    const uint32_t so_ = (uint32_t)((size_t)(key0_) * rowstride);                                 \
+    if ((key0_) + 64 <= p.t) {                                                                    \
+      _Pragma("unroll") for (int u = 0; u < NCH; ++u) { pk[u] = X3_LD(koff[u], so_); pv[u] = X3_LD(koff[u], so_ + v_plane); }      \
+    } else {                                                                                      \
+      _Pragma("unroll") for (int u = 0; u < NCH; ++u) {                                           \
+        const uint32_t vo_ = ((key0_) + (tid >> 4) + 16 * u < p.t) ? koff[u] : 0x80000000u;       \
+        pk[u] = X3_LD(vo_, so_); pv[u] = X3_LD(vo_, so_ + v_plane);                               \
+      }                                                                                           \
     }                                                                                             \
   }
+  const uint32_t st_off = (uint32_t)((tid >> 4) * ROWB + (tid & 15) * 16);               // LDS slot of chunk (row tid >> 4, c); + 16 u rows
 #define X3_STAGE_TILE()                                                                           \
   _Pragma("unroll") for (int u = 0; u < NCH; ++u) {                                               \
-    const int idx = tid + 256 * u, r = idx / CH, c = idx - r * CH;                                \
-    *reinterpret_cast<uint4*>(sK + r * ROWB + c * 16) = pk[u];                                    \
-    *reinterpret_cast<uint4*>(sV + r * ROWB + c * 16) = pv[u];                                    \
+    *reinterpret_cast<uint4*>(sK + st_off + u * (16 * ROWB)) = pk[u];                             \
+    *reinterpret_cast<uint4*>(sV + st_off + u * (16 * ROWB)) = pv[u];                             \
   }
   X3_LOAD_TILE(0);
   for (int kt = 0; kt < ntiles; ++kt) {
@@ -482,14 +506,34 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const AttP p) {
     if (kt + 1 < ntiles) { X3_LOAD_TILE(key0 + 64); }
     // ---- S^T * 2^12: a K fragment pair feeds every query tile
     f32x4_t sacc[QT][4];
+    // the fragments of key group j + 1 are requested BEFORE the MFMAs of group j are issued (two register sets): in the former order the
+    // four reads of a group went out behind the previous group's MFMAs and the wave then waited a whole LDS round trip for them, four
+    // times per key tile (ISA trace, round 6: RRRR wait MMMM.. RRRR wait ..) -- with two waves per SIMD nothing else covers that wait
+    uint4 kf[2][KSTEPS][2];
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      kf[0][s][0] = *reinterpret_cast<const uint4*>(sK + lq * ROWB + (lg + 4 * s) * 16);
+      kf[0][s][1] = *reinterpret_cast<const uint4*>(sK + lq * ROWB + D * ES + (lg + 4 * s) * 16);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) sacc[qt][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if (KPRE && j < 3) {
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+          kf[(j + 1) & 1][s][0] = *reinterpret_cast<const uint4*>(sK + ((j + 1) * 16 + lq) * ROWB + (lg + 4 * s) * 16);
+          kf[(j + 1) & 1][s][1] = *reinterpret_cast<const uint4*>(sK + ((j + 1) * 16 + lq) * ROWB + D * ES + (lg + 4 * s) * 16);
+        }
+      }
+      if constexpr (KPRE) __builtin_amdgcn_sched_barrier(0);               // (keep the requests in front of this group's MFMAs)
 #pragma unroll
       for (int s = 0; s < KSTEPS; ++s) {
-        const uint4 kh = *reinterpret_cast<const uint4*>(sK + (j * 16 + lq) * ROWB + (lg + 4 * s) * 16);
-        const uint4 kl = *reinterpret_cast<const uint4*>(sK + (j * 16 + lq) * ROWB + D * ES + (lg + 4 * s) * 16);
+        uint4 kh = kf[j & 1][s][0], kl = kf[j & 1][s][1];
+        if (!KPRE && j > 0) {
+          kh = *reinterpret_cast<const uint4*>(sK + (j * 16 + lq) * ROWB + (lg + 4 * s) * 16);
+          kl = *reinterpret_cast<const uint4*>(sK + (j * 16 + lq) * ROWB + D * ES + (lg + 4 * s) * 16);
+        }
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
           sacc[qt][j] = AttMma<T>::run(kh, qh[qt][s], sacc[qt][j]);
@@ -498,8 +542,27 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const AttP p) {
         }
       }
     }
-    // ---- online softmax (attention16_kernel's), then P * 2^14 as (hi, lo) operand pairs
+    // V^T fragment pair (hi, lo) of key half kk, value tile dt: four transposing reads
+#define X3_VFRAG(kk_, dt_, avh_, avl_)                                                                                                    \
+  {                                                                                                                                       \
+    const char* va_ = sV + (32 * (kk_) + 4 * lg + ((lane & 15) >> 2)) * ROWB + (lane & 3) * 8 + (dt_) * 32;                                \
+    const uint2 h0_ = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(va_)));               \
+    const uint2 h1_ = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(va_ + 16 * ROWB)));   \
+    const uint2 l0_ = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(va_ + D * ES)));      \
+    const uint2 l1_ = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(va_ + 16 * ROWB + D * ES))); \
+    avh_ = make_uint4(h0_.x, h0_.y, h1_.x, h1_.y); avl_ = make_uint4(l0_.x, l0_.y, l1_.x, l1_.y);                                          \
+  }
+    // the first V^T fragments do not depend on the softmax: requested HERE, their LDS round trip runs under its vector work instead of in
+    // front of the first P.V MFMA
+    constexpr int VPRE = (VAR & 4) ? 2 : 0;
+    uint4 vpre[VPRE > 0 ? VPRE : 1][2];
+#pragma unroll
+    for (int dt = 0; dt < VPRE; ++dt) X3_VFRAG(0, dt, vpre[dt][0], vpre[dt][1]);
+    // ---- online softmax (attention16_kernel's), then P * 2^14 as (hi, lo) operand pairs.  Both query tiles' row maxima first: their
+    // cross-lane exchanges (three independent permutes per tile) are all in flight before the first is awaited -- one crossbar round trip
+    // per key tile instead of four dependent ones
     uint4 pbh[QT][2], pbl[QT][2];
+    float tmx[QT], t16[QT], t32[QT], t48[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       if (key0 + 64 > p.t) {
@@ -516,9 +579,19 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const AttP p) {
       tmax = vmax3(tmax, sacc[qt][2][1], sacc[qt][2][2]);
       tmax = vmax3(tmax, sacc[qt][2][3], sacc[qt][3][0]);
       tmax = vmax3(tmax, sacc[qt][3][1], sacc[qt][3][2]);
-      tmax = vmax2(tmax, sacc[qt][3][3]);
-      tmax = vmax2(tmax, __shfl_xor(tmax, 16, 64));
-      tmax = vmax2(tmax, __shfl_xor(tmax, 32, 64));
+      tmx[qt] = vmax2(tmax, sacc[qt][3][3]);
+    }
+    if constexpr (SM2) {
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        t16[qt] = __shfl_xor(tmx[qt], 16, 64); t32[qt] = __shfl_xor(tmx[qt], 32, 64); t48[qt] = __shfl_xor(tmx[qt], 48, 64);
+      }
+    }
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      float tmax;
+      if constexpr (SM2) tmax = vmax2(vmax3(tmx[qt], t16[qt], t32[qt]), t48[qt]);
+      else { tmax = vmax2(tmx[qt], __shfl_xor(tmx[qt], 16, 64)); tmax = vmax2(tmax, __shfl_xor(tmax, 32, 64)); }
       const float m_new = vmax2(m_run[qt], tmax);
       const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * sc2);
       const float mb = m_new * sc2 - 14.0f;             // exp2(.. + 14): P * 2^14 straight out of the exponential
@@ -528,30 +601,32 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const AttP p) {
         for (int i = 0; i < DT; ++i) o[qt][i] *= alpha;
         ol[qt][0] *= alpha;
       }
-      float ph[4][4], pl[4][4];
+      // P * 2^14 = hi + lo, two values at a time: the hi halves come out of ONE packed conversion (round to nearest even, as the scalar one), the
+      // lo halves are e - hi with the f16 operand widened inside the instruction (v_fma_mix_f32: exact, the product and the sum are
+      // representable) and packed.  The former scalar form converted every hi twice and cost 4.1 vector instructions per value, this costs 2.5.
+      uint32_t hw_[4][2], lw_[4][2];
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(fmaf(sacc[qt][j][r], sc2, -mb));
-          const float h = f16_bits_to_f32(f32_to_f16_bits(e));
-          ph[j][r] = h;
-          pl[j][r] = e - h;
+        for (int r = 0; r < 4; r += 2) {
+          const float e0 = __builtin_amdgcn_exp2f(fmaf(sacc[qt][j][r], sc2, -mb));
+          const float e1 = __builtin_amdgcn_exp2f(fmaf(sacc[qt][j][r + 1], sc2, -mb));
+          const dts_f32x2_t ev = {e0, e1};
+          const dts_f16x2_t hv = __builtin_convertvector(ev, dts_f16x2_t);
+          const float l0 = __builtin_fmaf((float)hv[0], -1.0f, e0), l1 = __builtin_fmaf((float)hv[1], -1.0f, e1);
+          hw_[j][r >> 1] = __builtin_bit_cast(uint32_t, hv);
+          lw_[j][r >> 1] = pack2_f16(l0, l1);
         }
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
-        pbh[qt][kk].x = pack2_f16(ph[2 * kk][0], ph[2 * kk][1]);         pbh[qt][kk].y = pack2_f16(ph[2 * kk][2], ph[2 * kk][3]);
-        pbh[qt][kk].z = pack2_f16(ph[2 * kk + 1][0], ph[2 * kk + 1][1]); pbh[qt][kk].w = pack2_f16(ph[2 * kk + 1][2], ph[2 * kk + 1][3]);
-        pbl[qt][kk].x = pack2_f16(pl[2 * kk][0], pl[2 * kk][1]);         pbl[qt][kk].y = pack2_f16(pl[2 * kk][2], pl[2 * kk][3]);
-        pbl[qt][kk].z = pack2_f16(pl[2 * kk + 1][0], pl[2 * kk + 1][1]); pbl[qt][kk].w = pack2_f16(pl[2 * kk + 1][2], pl[2 * kk + 1][3]);
+        pbh[qt][kk] = make_uint4(hw_[2 * kk][0], hw_[2 * kk][1], hw_[2 * kk + 1][0], hw_[2 * kk + 1][1]);
+        pbl[qt][kk] = make_uint4(lw_[2 * kk][0], lw_[2 * kk][1], lw_[2 * kk + 1][0], lw_[2 * kk + 1][1]);
       }
     }
-    // ---- O^T * 2^20 and l * 2^14; a V^T fragment pair feeds every query tile
+    // ---- O^T * 2^20 and l * 2^14; a V^T fragment pair feeds every query tile.  (The first VPRE fragment pairs were requested before the
+    // softmax, see above.)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      const int rq = (lane & 15) >> 2, rp = lane & 3;
-      const char* va = sV + (32 * kk + 4 * lg + rq) * ROWB + rp * 8;
-      const char* vb = va + 16 * ROWB;
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
         ol[qt] = AttMma<T>::run(ones, pbh[qt][kk], ol[qt]);
@@ -559,11 +634,9 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const AttP p) {
       }
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        const uint2 h0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(va + dt * 32)));
-        const uint2 h1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vb + dt * 32)));
-        const uint2 l0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(va + D * ES + dt * 32)));
-        const uint2 l1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vb + D * ES + dt * 32)));
-        const uint4 avh = make_uint4(h0.x, h0.y, h1.x, h1.y), avl = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        uint4 avh, avl;
+        if (kk == 0 && dt < VPRE) { avh = vpre[dt][0]; avl = vpre[dt][1]; }
+        else X3_VFRAG(kk, dt, avh, avl);
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
           o[qt][dt] = AttMma<T>::run(avh, pbh[qt][kk], o[qt][dt]);
@@ -573,7 +646,9 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const AttP p) {
       }
     }
   }
+#undef X3_VFRAG
 #undef X3_LOAD_TILE
+#undef X3_LD
 #undef X3_STAGE_TILE
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
@@ -787,8 +862,14 @@ extern "C" int dts_attention_x3(const void* qkv_split, void* out, int out_split3
   AttP p{(const char*)qkv_split, (char*)out, n, t, heads, d, scale * 1.4426950408889634f, 0, 1, out_split3 ? 1 : 0};
   const size_t lds = (size_t)2 * 64 * (2 * 64 * 2 + 32);
   // two query tiles per wave once the sequence is long enough to keep >= 2 blocks per CU in the grid (the rule of the 16-bit kernel)
-  if (t >= 256 && (long long)((t + 127) / 128) * n * heads >= 512) return launch_att(attention_x3_kernel<2>, p, lds, to_stream(s), 128);
-  return launch_att(attention_x3_kernel<1>, p, lds, to_stream(s));
+  const int qt = dts_knob_get(DTS_KNOB_ATT_QT);            // DTS_ATT_QT = 1 | 2 forces a form (A/B aid, tools/att_bench.py --x3-kernel)
+  // (round 6: one query tile per wave below 512 tokens -- 140 registers, three waves per SIMD: T = 256 at 64 rows 49.3 -> 43.8 us, tools/att_bench.py --x3-kernel)
+  const bool two = qt == 2 || (qt != 1 && t >= 512 && (long long)((t + 127) / 128) * n * heads >= 512);
+  const int var = dts_knob_get(DTS_KNOB_ATT_DB) >= 16 ? dts_knob_get(DTS_KNOB_ATT_DB) - 16 : 7;
+#define X3_LAUNCH(V_) (two ? launch_att(attention_x3_kernel<2, V_>, p, lds, to_stream(s), 128) : launch_att(attention_x3_kernel<1, V_>, p, lds, to_stream(s)))
+  if (var == 0) return X3_LAUNCH(0);      // DTS_ATT_DB=16: without the three latency changes of round 6 (A/B aid, tools/att_bench.py --x3-kernel --variants 0)
+  return X3_LAUNCH(7);
+#undef X3_LAUNCH
 }
 
 extern "C" int dts_attention(const void* qkv, void* out, int dtype, int n, int t, int heads, int d, float scale, dts_stream s) {

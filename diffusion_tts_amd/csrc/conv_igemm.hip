@@ -479,9 +479,21 @@ __device__ __forceinline__ void conv_epilogue_rows_f32(const ConvP& kp, f32x4_t 
         float hi[4], lo[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) x2_split(v[r], hi[r], lo[r]);
-        f16_t* orow = reinterpret_cast<f16_t*>(kp.out) + 2 * (prow[u] - co) + co;
-        *reinterpret_cast<uint2*>(orow) = make_uint2(pack2_f16(hi[0], hi[1]), pack2_f16(hi[2], hi[3]));
-        *reinterpret_cast<uint2*>(orow + p_cout) = make_uint2(pack2_f16(lo[0], lo[1]), pack2_f16(lo[2], lo[3]));
+        // lanes c4 = 2m / 2m + 1 hold couts 8m .. 8m+3 / 8m+4 .. 8m+7 of the same pixel (LPR is even, so lane parity = c4 parity): the pair swaps
+        // halves (one DPP quad permute per dword) and the even lane stores 16 bytes of the hi plane, the odd lane 16 bytes of the lo plane --
+        // half the store instructions of the two 8-byte stores per lane (the epilogue is store-issue bound), same bits
+        const uint2 h = make_uint2(pack2_f16(hi[0], hi[1]), pack2_f16(hi[2], hi[3])), l = make_uint2(pack2_f16(lo[0], lo[1]), pack2_f16(lo[2], lo[3]));
+        const bool odd = (c4 & 1) != 0;
+        const uint32_t rx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(odd ? h.x : l.x), 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
+        const uint32_t ry = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(odd ? h.y : l.y), 0xB1, 0xf, 0xf, false);
+        if (kp.epi_rows == 2) {                        // (A/B aid, DTS_CONV_EPI32=2: the former two 8-byte stores per lane)
+          f16_t* o8 = reinterpret_cast<f16_t*>(kp.out) + 2 * (prow[u] - co) + co;
+          *reinterpret_cast<uint2*>(o8) = h;
+          *reinterpret_cast<uint2*>(o8 + p_cout) = l;
+          continue;
+        }
+        f16_t* orow = reinterpret_cast<f16_t*>(kp.out) + 2 * (prow[u] - co) + (odd ? co - 4 + p_cout : co);
+        *reinterpret_cast<uint4*>(orow) = odd ? make_uint4(rx, ry, l.x, l.y) : make_uint4(h.x, h.y, rx, ry);
       } else {
         const f32x4_nt o = {v[0], v[1], v[2], v[3]};
         __builtin_nontemporal_store(o, reinterpret_cast<f32x4_nt*>(reinterpret_cast<float*>(kp.out) + prow[u]));
@@ -1910,7 +1922,7 @@ extern "C" int dts_conv2d(dts_conv_args* a, dts_stream s) {
   {   // the row-layout f32 epilogue: the split-precision mode's default; the f32 parity mode keeps the accumulator-layout epilogue (the mode is the
       // REFERENCE the others are compared with: its summation orders stay what rounds 2-4 validated against the CPU oracle) unless DTS_CONV_EPI32=1
     const int k_ = dts_knob_get(DTS_KNOB_CONV_EPI32);
-    p.epi_rows = k_ < 0 ? (a->dtype == DTS_F16X3 ? 1 : 0) : (k_ != 0);
+    p.epi_rows = k_ < 0 ? (a->dtype == DTS_F16X3 ? 1 : 0) : (k_ == 2 ? 2 : (k_ != 0));
   }
   DTS_CHECK_ARG(a->gn_coef == nullptr || dts_conv_fuses_gn(a), "dts_conv2d: gn_coef given for a launch that cannot fuse the GroupNorm apply "
                 "(ask dts_conv_fuses_gn first)");

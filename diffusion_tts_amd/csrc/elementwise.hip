@@ -459,13 +459,25 @@ __global__ __launch_bounds__(256) void candidate_noise_sd_kernel(const T* __rest
   st1<T>(&nrm_t, sqrtf((red[0] + red[1]) + (red[2] + red[3])));
   // `to_add * rand * lambda * sqrt(numel)` (:1379) is ((to_add * rand) * lambda) * sqrt: three tensor-by-scalar products, each rounded to T
   // (torch multiplies in f32 with the scalar cast to f32 and rounds the result to the tensor's type)
-  const float nrm = ld1<T>(&nrm_t), s0 = scale[3 * cn], s1 = scale[3 * cn + 1], s2 = scale[3 * cn + 2];
+  float nrm = ld1<T>(&nrm_t);
+  // (hidden from the optimiser: with both operands visibly widened from T it narrows the quotient to a HALF-precision division, which the
+  // target lowers through v_rcp_f16 -- one ulp off torch's float division rounded once; tests/test_gpu_sd.py checks bit equality)
+  asm volatile("" : "+v"(nrm));
+  const float s0 = scale[3 * cn], s1 = scale[3 * cn + 1], s2 = scale[3 * cn + 2];
   for (int i = threadIdx.x; i < count; i += blockDim.x) {
     T a, b, c;
     st1<T>(&a, ld1<T>(ur + i) / nrm);                         // to_add / torch.norm(to_add)
-    st1<T>(&b, ld1<T>(&a) * s0);                              // * torch.rand(1).item()
-    st1<T>(&a, ld1<T>(&b) * s1);                              // * params['lambda']
-    st1<T>(&b, ld1<T>(&a) * s2);                              // * np.sqrt(numel)
+    // each product is rounded to f32 FIRST and then to T, as torch does (f32 arithmetic, result cast to the tensor's type): left to itself the
+    // compiler fuses multiply and narrowing into v_fma_mixlo_f16 -- ONE rounding, which differs from the double rounding in ~1e-4 of the values
+    float t_ = ld1<T>(&a) * s0;                               // * torch.rand(1).item()
+    asm volatile("" : "+v"(t_));
+    st1<T>(&b, t_);
+    t_ = ld1<T>(&b) * s1;                                     // * params['lambda']
+    asm volatile("" : "+v"(t_));
+    st1<T>(&a, t_);
+    t_ = ld1<T>(&a) * s2;                                     // * np.sqrt(numel)
+    asm volatile("" : "+v"(t_));
+    st1<T>(&b, t_);
     st1<T>(&c, ld1<T>(pivot + i) + ld1<T>(&b));               // pivot + ...
     out[i] = c;
   }

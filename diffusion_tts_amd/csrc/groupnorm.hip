@@ -183,10 +183,31 @@ __device__ __forceinline__ void store_split4(f16_t* orow, int c0, const float* f
   *reinterpret_cast<uint2*>(d + 32) = make_uint2(pack2_f16(lo[0], lo[1]), pack2_f16(lo[2], lo[3]));
 }
 
+// The same output through 16-byte stores (round 6): lanes 2m / 2m+1 of a wave hold channels 8m'..8m'+3 / 8m'+4..8m'+7 of ONE pixel (a block's
+// threads are [pixel row][chunk] with an even chunk count, so lane parity = chunk parity).  The pair swaps halves with one DPP quad
+// permute per dword: the even lane stores the hi halves of all 8 channels (16 bytes), the odd lane their lo halves -- one store instruction
+// per pixel row and thread that covers WHOLE 128-byte lines (hi(32) | lo(32) of a 32-channel group = 8 lanes x 16 bytes) instead of two
+// 8-byte-per-lane instructions that each write half of every line.  Same bits.
+__device__ __forceinline__ uint32_t dpp_swap_pair(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);         // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ void store_split4_paired(f16_t* orow, int c0, const float* f, bool odd) {
+  float hi[4], lo[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) x3_split(f[e], hi[e], lo[e]);
+  const uint2 h = make_uint2(pack2_f16(hi[0], hi[1]), pack2_f16(hi[2], hi[3])), l = make_uint2(pack2_f16(lo[0], lo[1]), pack2_f16(lo[2], lo[3]));
+  // even lane sends its lo half and receives the partner's hi half; odd lane the other way round
+  const uint32_t sx = odd ? h.x : l.x, sy = odd ? h.y : l.y;
+  const uint32_t rx = dpp_swap_pair(sx), ry = dpp_swap_pair(sy);
+  const uint4 v = odd ? make_uint4(rx, ry, l.x, l.y) : make_uint4(h.x, h.y, rx, ry);
+  f16_t* d = orow + x3_off(odd ? c0 - 4 : c0) + (odd ? 32 : 0);
+  *reinterpret_cast<uint4*>(d) = v;
+}
+
 // Apply pass, row form: a block works on a pixel range of ONE sample and every thread keeps ONE 16-byte channel chunk, so
 // its (a,b) coefficients are loaded once and the loop body is load -> fma/SiLU -> store with no index arithmetic (the
 // grid-stride form below spends more VALU cycles on 64-bit div/mod per element than on the SiLU).  blockDim = k * nchunk.
-template <typename T, bool SPLIT = false>
+template <typename T, bool SPLIT = false, bool W16 = false>
 __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const T* __restrict__ x1, int c1, const T* __restrict__ x2, int c2,
                                                              const float* __restrict__ coef, T* __restrict__ out, int hw, int ppb,
                                                              int silu, f16_t* __restrict__ raw = nullptr) {
@@ -198,6 +219,8 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const T* __restrict_
   const int k = blockDim.x / nchunk;
   const int pr = threadIdx.x / nchunk, chunk = threadIdx.x - pr * nchunk;
   const int n = blockIdx.y, c0 = chunk * EPV;
+  const bool odd = (chunk & 1) != 0;
+#define DTS_STORE_SPLIT(orow_, f_) { if constexpr (W16) store_split4_paired(orow_, c0, f_, odd); else store_split4(orow_, c0, f_); }
   float A[EPV], B[EPV];
 #pragma unroll
   for (int e = 0; e < EPV; e += 2) {
@@ -219,7 +242,7 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const T* __restrict_
     unpack16<T>(v0, f0);
     unpack16<T>(v1, f1);
     if constexpr (SPLIT) {
-      if (raw3) { store_split4(raw3 + (size_t)p * 2 * C, c0, f0); store_split4(raw3 + (size_t)(p + k) * 2 * C, c0, f1); }
+      if (raw3) { DTS_STORE_SPLIT(raw3 + (size_t)p * 2 * C, f0); DTS_STORE_SPLIT(raw3 + (size_t)(p + k) * 2 * C, f1); }
     }
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
@@ -228,8 +251,8 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const T* __restrict_
       f1[e] = silu ? silu_t<T>(y1) : y1;
     }
     if constexpr (SPLIT) {
-      store_split4(dst3 + (size_t)p * 2 * C, c0, f0);
-      store_split4(dst3 + (size_t)(p + k) * 2 * C, c0, f1);
+      DTS_STORE_SPLIT(dst3 + (size_t)p * 2 * C, f0);
+      DTS_STORE_SPLIT(dst3 + (size_t)(p + k) * 2 * C, f1);
     } else {
       *reinterpret_cast<uint4*>(dst + (size_t)p * C) = pack16<T>(f0);
       *reinterpret_cast<uint4*>(dst + (size_t)(p + k) * C) = pack16<T>(f1);
@@ -240,14 +263,15 @@ __global__ __launch_bounds__(256) void gn_apply_rows_kernel(const T* __restrict_
     float f0[EPV];
     unpack16<T>(v0, f0);
     if constexpr (SPLIT) {
-      if (raw3) store_split4(raw3 + (size_t)p * 2 * C, c0, f0);
+      if (raw3) DTS_STORE_SPLIT(raw3 + (size_t)p * 2 * C, f0);
     }
 #pragma unroll
     for (int e = 0; e < EPV; ++e) { const float y0 = f0[e] * A[e] + B[e]; f0[e] = silu ? silu_t<T>(y0) : y0; }
-    if constexpr (SPLIT) store_split4(dst3 + (size_t)p * 2 * C, c0, f0);
+    if constexpr (SPLIT) DTS_STORE_SPLIT(dst3 + (size_t)p * 2 * C, f0)
     else *reinterpret_cast<uint4*>(dst + (size_t)p * C) = pack16<T>(f0);
   }
 }
+#undef DTS_STORE_SPLIT
 
 template <typename T, bool POOL, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x1, int c1, const T* __restrict__ x2, int c2,
@@ -512,6 +536,12 @@ static int gn_apply_impl(const void* x1, int c1, const void* x2, int c2, int dty
       const int nchunk = C / epv, k = 256 / nchunk, hw = h * w;
       long long ppb = ((long long)n * hw + 4095) / 4096;
       ppb = ((ppb + 2 * k - 1) / (2 * k)) * (2 * k);
+      // (W16: whole-line 16-byte stores through a lane-pair exchange; needs the pair's two chunks on one side of the concat boundary: c1 % 8 == 0.
+      //  DTS_GN_FUSE=2 selects the 8-byte-store form for A/B runs)
+      if (c1 % 8 == 0 && dts_knob_get(DTS_KNOB_GN_FUSE) != 2)
+        hipLaunchKernelGGL((gn_apply_rows_kernel<T, true, true>), dim3((unsigned)((hw + ppb - 1) / ppb), n), dim3(k * nchunk), 0, st, (const T*)x1, c1,
+                           (const T*)x2, c2, coef, (T*)out, hw, (int)ppb, silu, (f16_t*)raw_out);
+      else
       hipLaunchKernelGGL((gn_apply_rows_kernel<T, true>), dim3((unsigned)((hw + ppb - 1) / ppb), n), dim3(k * nchunk), 0, st, (const T*)x1, c1,
                          (const T*)x2, c2, coef, (T*)out, hw, (int)ppb, silu, (f16_t*)raw_out);
     } else

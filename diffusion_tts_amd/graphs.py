@@ -12,9 +12,10 @@ small graph's private pool is small.
 Not a tracing compiler: nothing is rewritten or fused, the graph is the eager launch sequence.  The first calls of a shape run
 eagerly (they also perform the one-time `hipFuncSetAttribute` calls), the third is captured; a module stops capturing new
 shapes after 8 captures (MCTS rollouts change their batch size all the time).  `DTS_GRAPHS=0` disables it.
-A refused capture is an ERROR (the product must not run 3-5x slower at small batches behind a Python warning, and a measurement must
-not report eager-launch numbers under the graph-replay name); `DTS_GRAPHS_STRICT=0` opts into the eager fallback explicitly, and then
-`GraphCache.fallback` records why.  `path_report()` says which path a module's forwards took (main.py prints it)."""
+A refused capture (an out-of-memory private pool on the Nth ragged MCTS batch size, say) must not abort a long search -- nor, in a sharded
+run, leave the other ranks waiting in the next collective: the SHAPE that was refused stays on eager launches (same kernels), a warning says
+so once, `GraphCache.fallback` records why and `path_report()` shows it (main.py prints it).  A measurement must not report eager-launch
+numbers under the graph-replay name: `DTS_GRAPHS_STRICT=1` (set by bench.py, the tools and the test-suite) turns a refusal into an error."""
 import gc
 import math
 import os
@@ -46,7 +47,8 @@ class GraphCache:
         self.captures = 0
         self.captures_by_class = [0, 0]  # [large, small]
         self.eager = 0                  # forwards launched kernel by kernel (first sightings of a shape, shapes beyond MAX_CAPTURES, graphs off)
-        self.fallback = None            # why capturing stopped (only with DTS_GRAPHS_STRICT=0)
+        self.fallback = None            # why a capture was refused (the last refusal; without DTS_GRAPHS_STRICT=1)
+        self.refused = set()            # shapes whose capture was refused: they stay on eager launches
 
     @property
     def fn(self):
@@ -65,7 +67,7 @@ class GraphCache:
         if ent is None:
             self.seen[key] = self.seen.get(key, 0) + 1
             small = self._small(key)
-            if self.seen[key] < SIGHTINGS or self.captures_by_class[small] >= (MAX_CAPTURES_SMALL if small else MAX_CAPTURES):
+            if key in self.refused or self.seen[key] < SIGHTINGS or self.captures_by_class[small] >= (MAX_CAPTURES_SMALL if small else MAX_CAPTURES):
                 self.eager += 1
                 return self.fn(*inputs)
             ent = self._capture(key, inputs)
@@ -102,11 +104,12 @@ class GraphCache:
             with torch.cuda.graph(graph):
                 static_out = fn(*static_in)
         except Exception as e:                       # capture refused: stay on the eager launch sequence (same kernels)
-            if os.environ.get('DTS_GRAPHS_STRICT', '1') != '0':
-                raise RuntimeError(f'HIP-graph capture failed ({type(e).__name__}: {e}); set DTS_GRAPHS_STRICT=0 to continue with eager '
-                                   f'launches (same kernels, several times slower at small batches) or DTS_GRAPHS=0 to never capture') from e
-            warnings.warn(f'HIP-graph capture failed ({type(e).__name__}: {e}); DTS_GRAPHS_STRICT=0: continuing with eager launches')
-            self.enabled = False
+            if os.environ.get('DTS_GRAPHS_STRICT', '0') == '1':
+                raise RuntimeError(f'HIP-graph capture failed ({type(e).__name__}: {e}); DTS_GRAPHS_STRICT=1: not continuing on eager launches '
+                                   f'(same kernels, several times slower at small batches)') from e
+            warnings.warn(f'HIP-graph capture of shape {key} failed ({type(e).__name__}: {e}): this shape continues on eager launches '
+                          f'(DTS_GRAPHS_STRICT=1 makes this an error)')
+            self.refused.add(key)
             self.fallback = f'{type(e).__name__}: {e}'
             return None
         finally:
@@ -124,5 +127,5 @@ class GraphCache:
     def path_report(self):
         """which path this module's forwards took so far"""
         how = 'HIP-graph replay' if self.replays else ('eager launches' if self.eager else 'no forward yet')
-        extra = f'; capture refused: {self.fallback}' if self.fallback else ('' if self.enabled else '; graphs disabled')
+        extra = f'; capture refused for {len(self.refused)} shape(s): {self.fallback}' if self.fallback else ('' if self.enabled else '; graphs disabled')
         return f'{how} ({self.replays} replays of {self.captures} captured graphs, {self.eager} eager forwards{extra})'

@@ -10,6 +10,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+os.environ.setdefault('DTS_GRAPHS_STRICT', '1')      # a refused HIP-graph capture fails a test instead of quietly measuring / checking eager launches
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 

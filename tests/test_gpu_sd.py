@@ -82,7 +82,14 @@ def test_candidate_noise_sd_rounds_like_the_reference_expression(dtype):
     scale = torch.tensor([[r, lam, root] if m_ else [0.0, 0.0, 0.0] for r, m_ in zip(rands, mode.tolist())], dtype=torch.float32)
     got = ops.candidate_noise_sd(pivot.to(DEV), u.to(DEV), mode.to(DEV), scale.to(DEV)).cpu()
     if dtype == torch.float16:
-        assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+        if not torch.equal(got, want):              # say where and by how much before failing
+            bad = (got != want)
+            per = bad.reshape(n, -1).sum(dim=1).tolist()
+            idx = bad.reshape(-1).nonzero().reshape(-1)[:6].tolist()
+            uf = u.float().reshape(-1)
+            detail = [(i_, float(got.reshape(-1)[i_]), float(want.reshape(-1)[i_]), float(uf[i_]), float(pivot.reshape(-1)[i_ % pivot.numel()])) for i_ in idx]
+            raise AssertionError(f'{int(bad.sum())} of {bad.numel()} values differ, per candidate {per}; (index, got, want, u, pivot): {detail}; '
+                                 f'norms {[float(torch.norm(u[c_])) for c_ in range(n)]}')
     else:
         assert float((got - want).abs().max()) <= 2 ** -22 * float(want.abs().max())
         assert torch.equal(got[1], want[1]) and torch.equal(got[4], want[4])

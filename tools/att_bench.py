@@ -47,15 +47,56 @@ def x3_table(a):
         print(f'{name:20s} T={t:5d} | f32 {res[0] * 1e3:7.1f} us {fl / res[0] / 1e9:6.1f} TF/s | f16x3 {res[1] * 1e3:7.1f} us {fl / res[1] / 1e9:6.1f} TF/s (algorithmic) | f16 {res[2] * 1e3:7.1f} us', flush=True)
 
 
+def x3_kernel_table(a):
+    """attention_x3_kernel alone, as the network calls it inside an attention block: the qkv projection's split image in, the proj
+    convolution's split image out; DTS_ATT_QT = 1 | 2 (query tiles per wave) interleaved against the launcher's rule, outputs compared."""
+    print('attention_x3_kernel on a split qkv image (split image out), us per launch: launcher rule | att_qt=1 | att_qt=2' + ''.join(f' | variant {d_}' for d_ in a.variants_x3))
+    for name, t, heads, d in SHAPES:
+        if d != 64 or t < 128:
+            continue
+        c = heads * d
+        sp = ops.SplitQKV(torch.empty(0), (a.n, t, 1, 3 * c))
+        sp.data = torch.empty((a.n, t, 6 * c), dtype=torch.float16, device='cuda')
+        ops._call('dts_split2_f16', ops._ptr(torch.randn(a.n, t, 3 * c, device='cuda'), 'qkv', torch.float32), 3 * c, ops._ptr(sp.data), a.n * t)
+        fl = 4.0 * a.n * heads * t * t * d
+        outs, res = [], []
+        variants = [(-1, -1), (1, -1), (2, -1)] + [(-1, 16 + d_) for d_ in a.variants_x3]
+        ts = [[] for _ in variants]
+        for r in range(a.rounds + 1):
+            for vi, (q, db) in enumerate(variants):
+                _lib.set_tuning('att_qt', q)
+                _lib.set_tuning('att_db', db)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda._sleep(200_000)
+                e0.record()
+                for _ in range(4):
+                    o = ops.attention(sp.view(a.n, t, 3 * c), heads, d ** -0.5, x3=True, split_out=True)
+                e1.record()
+                torch.cuda.synchronize()
+                if r:
+                    ts[vi].append(e0.elapsed_time(e1) / 4)
+                else:
+                    outs.append(o.data.clone())
+        _lib.set_tuning('att_qt', -1)
+        _lib.set_tuning('att_db', -1)
+        med = [sorted(t_)[len(t_) // 2] for t_ in ts]
+        same = all(torch.equal(outs[0], o_) for o_ in outs[1:])
+        print(f'{name:20s} T={t:5d} | ' + ' | '.join(f'{m * 1e3:7.1f} us {fl / m / 1e9:6.1f} TF/s' for m in med) + f' | outputs {"identical" if same else "DIFFER"}', flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--n', type=int, default=64)
     ap.add_argument('--dtype', default='bf16')
     ap.add_argument('--rounds', type=int, default=9)
     ap.add_argument('--variants', nargs='*', default=['att_xcd=0', 'att_xcd=1'])
+    ap.add_argument('--variants-x3', type=int, nargs='*', default=[], help='(--x3-kernel) A/B: 0 = the kernel without the three latency changes of round 6 (K fragment prefetch, one-round max exchange, V prefetch)')
+    ap.add_argument('--x3-kernel', action='store_true', help='attention_x3_kernel alone on split images, att_qt variants')
     ap.add_argument('--x3', action='store_true', help='f32 qkv: the f32-MFMA kernel vs the split-precision kernel (split pass included)')
     a = ap.parse_args()
     dt = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[a.dtype]
+    if a.x3_kernel:
+        return x3_kernel_table(a)
     if a.x3:
         return x3_table(a)
     variants = [dict((kv.split('=')[0], int(kv.split('=')[1])) for kv in v.split(',')) for v in a.variants]
