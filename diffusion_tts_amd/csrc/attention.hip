@@ -682,6 +682,7 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const AttP p) {
   }
 }
 
+
 // ------------------------------------------------------------------------------------------------
 // f32 (parity) path: same structure on v_mfma_f32_16x16x4_f32; V needs no transpose (one k per lane group).
 template <int D>
@@ -865,7 +866,7 @@ extern "C" int dts_attention_x3(const void* qkv_split, void* out, int out_split3
   const int qt = dts_knob_get(DTS_KNOB_ATT_QT);            // DTS_ATT_QT = 1 | 2 forces a form (A/B aid, tools/att_bench.py --x3-kernel)
   // (round 6: one query tile per wave below 512 tokens -- 140 registers, three waves per SIMD: T = 256 at 64 rows 49.3 -> 43.8 us, tools/att_bench.py --x3-kernel)
   const bool two = qt == 2 || (qt != 1 && t >= 512 && (long long)((t + 127) / 128) * n * heads >= 512);
-  const int var = dts_knob_get(DTS_KNOB_ATT_DB) >= 16 ? dts_knob_get(DTS_KNOB_ATT_DB) - 16 : 7;
+  const int var = (dts_knob_get(DTS_KNOB_ATT_DB) >= 16 && dts_knob_get(DTS_KNOB_ATT_DB) < 32) ? dts_knob_get(DTS_KNOB_ATT_DB) - 16 : 7;
 #define X3_LAUNCH(V_) (two ? launch_att(attention_x3_kernel<2, V_>, p, lds, to_stream(s), 128) : launch_att(attention_x3_kernel<1, V_>, p, lds, to_stream(s)))
   if (var == 0) return X3_LAUNCH(0);      // DTS_ATT_DB=16: without the three latency changes of round 6 (A/B aid, tools/att_bench.py --x3-kernel --variants 0)
   return X3_LAUNCH(7);
