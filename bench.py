@@ -67,8 +67,8 @@ def _stale(doc):
     return None if d is None else d != csrc_digest()
 
 
-TRAFFIC_PROFILE = {'f16x3': 'profiles/r05_hbm_traffic_pmc_f16x3.json', 'bf16': 'profiles/r05_hbm_traffic_pmc_bf16.json'}
-ROCPROF_PROFILE = {'f16x3': 'profiles/r05_rocprof_dominant_f16x3.json', 'bf16': 'profiles/r05_rocprof_dominant_bf16.json'}
+TRAFFIC_PROFILE = {'f16x3': 'profiles/r06_hbm_traffic_pmc_f16x3.json', 'bf16': 'profiles/r06_hbm_traffic_pmc_bf16.json'}
+ROCPROF_PROFILE = {'f16x3': 'profiles/r06_rocprof_dominant_f16x3.json', 'bf16': 'profiles/r06_rocprof_dominant_bf16.json'}
 
 _T0 = time.perf_counter()
 

@@ -860,6 +860,8 @@ extern "C" int dts_attention_x3(const void* qkv_split, void* out, int out_split3
   DTS_CHECK_ARG(qkv_split && out, "dts_attention_x3: null pointer");
   DTS_CHECK_ARG(n > 0 && t > 0 && heads > 0, "dts_attention_x3: bad shape");
   DTS_CHECK_ARG(d == 64, "dts_attention_x3: head dim %d unsupported (64; other sizes take dts_attention in DTS_F32)", d);
+  // the key / value tiles are fetched with buffer loads: 32-bit byte offsets inside one sample's rows of 6 * heads * d f16
+  DTS_CHECK_ARG((long long)t * 6 * heads * d * 2 < (1ll << 31), "dts_attention_x3: %d tokens x %d heads exceed the 2 GiB a sample's rows may span", t, heads);
   AttP p{(const char*)qkv_split, (char*)out, n, t, heads, d, scale * 1.4426950408889634f, 0, 1, out_split3 ? 1 : 0};
   const size_t lds = (size_t)2 * 64 * (2 * 64 * 2 + 32);
   // two query tiles per wave once the sequence is long enough to keep >= 2 blocks per CU in the grid (the rule of the 16-bit kernel)

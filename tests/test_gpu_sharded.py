@@ -188,3 +188,86 @@ def test_sharded_sd_search_equals_single_process():
             assert np.abs(me['latents'] - ref['latents']).max() < 1e-5 and np.abs(me['image'] - ref['image']).max() < 1e-5, (method, r)
             assert me['decoded'] < ref['decoded'] and me['unet_rows'] < ref['unet_rows'], (method, r)
             assert me['collectives'] == (steps if method == 'beam' else steps * params['K']), (method, me['collectives'])
+
+
+# ---- BASELINE configs[2] AT FULL SIZE under real sharding, against the reference's own run ------------------------------
+def _worker_config3(rank, world, port, q, backend, chunk):
+    import json
+    import torch.distributed as dist
+    from conftest import ROOT
+    from helpers import full_weights
+    from diffusion_tts_amd import sampler as sm, scorers as S
+    from diffusion_tts_amd.networks import EDMPrecond
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if backend == 'nccl':
+        torch.cuda.set_device(rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        gd = os.path.join(ROOT, 'tests', 'golden')
+        gfull, g = np.load(os.path.join(gd, 'fullsize_golden.npz')), np.load(os.path.join(gd, 'config3_golden.npz'))
+        with open(os.path.join(gd, 'fullsize_manifest.json')) as f:
+            mfull = json.load(f)
+        with open(os.path.join(gd, 'config3_manifest.json')) as f:
+            m = json.load(f)
+        cfg, sd = full_weights(mfull, 'adm_imagenet64')
+        ccfg, csd = full_weights(mfull, 'cls_imagenet64')
+        net = EDMPrecond(cfg, sd, device='cuda')
+        scorer = S.ImageNetScorer(weights=csd, cfg=ccfg, device='cuda')
+        lat = torch.from_numpy(gfull['eg64_latents'])
+        lab = torch.eye(1000)[torch.from_numpy(gfull['eg64_label_idx']).long()]
+        h = sm.generate_image_grid(net, None, lat, lab, seed=m['seed'], gridw=1, gridh=1, device=torch.device('cuda'), num_steps=18,
+                                   sampling_method=sm.SamplingMethod.EPS_GREEDY, sampling_params=dict(scorer=scorer, **m['params']),
+                                   scale_fn=seed0_scale, verbose=False, forced_selections=[int(v) for v in g['selected']], candidate_chunk=chunk, **m['S'])
+        q.put((rank, dict(rewards=np.stack([r.reshape(-1).numpy() for r in h['rewards']]), own=[int(s_[0]) for s_ in h['selected']],
+                          x=h['x'].cpu().numpy(), image=h['image'][0].permute(1, 2, 0).numpy(), rows=int(h['net_rows']), collectives=int(h['collectives']),
+                          backend=dist.get_backend(), world=dist.get_world_size())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('backend', ['gloo', 'nccl'])
+def test_sharded_config3_walk_against_the_reference_run(backend):
+    """BASELINE configs[2] ("candidates sharded 8 x") at full network size, SHARDED, walked along the reference's own run of it
+    (tests/golden/config3_golden.npz): every rank evaluates its share of the 64 candidates in pieces of 8 -- the launch forms of one rank of
+    eight -- and the rewards meet in ONE all-gather per decision.  gloo: two ranks share the test box's GPU; nccl (RCCL, >= 2 GPUs): one rank
+    per GPU, up to eight.  On every rank: the 72 x 64 gathered rewards within 5e-8 of the reference's, the build's own argmax equal to the
+    reference's wherever its top-2 gap exceeds 4x the error, 72 collectives, the final state within 1e-3, the PNG within 1 LSB."""
+    import json
+    from conftest import ROOT
+    gd = os.path.join(ROOT, 'tests', 'golden')
+    if not os.path.exists(os.path.join(gd, 'config3_golden.npz')):
+        pytest.skip('tests/golden/config3_golden.npz not generated')
+    if backend == 'nccl' and torch.cuda.device_count() < 2:
+        pytest.skip('the RCCL variant needs 2 GPUs')
+    world = 2 if backend == 'gloo' else min(8, 1 << (torch.cuda.device_count().bit_length() - 1))
+    chunk = None if world == 8 else 8
+    g = np.load(os.path.join(gd, 'config3_golden.npz'))
+    with open(os.path.join(gd, 'config3_manifest.json')) as f:
+        m = json.load(f)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_config3, args=(r, world, port, q, backend, chunk)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=900) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ref_sel, gaps = [int(v) for v in g['selected']], m['top2_gaps']
+    for r in range(world):
+        me = got[r]
+        assert me['world'] == world and me['backend'] == backend and me['collectives'] == 72
+        assert me['rows'] == (17 * 4 * 2 + 4) * (64 // world) + 35         # this rank's candidates (two Heun stages, one at the last sigma step) + the replicated pivot steps
+        errs = np.abs(me['rewards'].astype(np.float64) - g['rewards'].astype(np.float64)).max(axis=1)
+        dec = [d for d in range(72) if gaps[d] > 0 and gaps[d] > 4 * errs[d]]
+        assert errs.max() < 5e-8 and len(dec) >= 40 and all(me['own'][d] == ref_sel[d] for d in dec), (r, float(errs.max()), len(dec))
+        assert all(me['own'][d] == 0 and np.all(me['rewards'][d] == me['rewards'][d][0]) for d in range(72) if gaps[d] == 0.0)
+        assert np.abs(me['x'] - g['last_D'].astype(np.float64)).max() < 1e-3
+        diff = np.abs(me['image'].astype(np.int32) - g['image'].astype(np.int32))
+        assert diff.max() <= 1 and (diff > 0).mean() < 0.005
+        assert np.array_equal(me['rewards'], got[0]['rewards']) and np.array_equal(me['x'], got[0]['x'])       # replicas agree bit for bit
+    print(f'config 3 sharded over {world} {backend} ranks (pieces of {chunk or 64 // world}): max reward error {float(np.abs(got[0]["rewards"].astype(np.float64) - g["rewards"].astype(np.float64)).max()):.2e}')

@@ -1,11 +1,11 @@
 #!/bin/bash
 # copies the summaries of tools/final_run.sh + tools/final_profiles.sh (gpurun_out/final_*) into profiles/ under the round's names:
-#   tools/collect_profiles.sh r05
+#   tools/collect_profiles.sh r06
 # and writes the two small JSON files per dtype that bench.py quotes in its line (roofline.traffic, roofline.rocprof_avg_launch_us):
 #   profiles/<rd>_hbm_traffic_pmc_<dtype>.json, profiles/<rd>_rocprof_dominant_<dtype>.json   (stamped with the commit they were collected at)
 set -e
 cd "$(dirname "$0")/.."
-RD=${1:-r05}; O=gpurun_out; HEAD=$(git rev-parse --short HEAD)
+RD=${1:-r06}; O=gpurun_out; HEAD=$(git rev-parse --short HEAD)
 cp "$(ls -t $O/final_prof_x3/*/*kernel_stats.csv | head -1)" profiles/${RD}_bench_kernel_stats.csv           # the headline mode (f16x3)
 cp "$(ls -t $O/final_prof_bf16/*/*kernel_stats.csv | head -1)" profiles/${RD}_bf16_kernel_stats.csv
 cp "$(ls -t $O/final_prof_c8/*/*kernel_stats.csv | head -1)" profiles/${RD}_c8_kernel_stats.csv

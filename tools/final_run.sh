@@ -20,6 +20,11 @@ DTS_SHARD_ALWAYS_COLLECT=1 NCCL_DEBUG=VERSION python bench.py --steps 6 --warmup
 NG=$(python -c "import torch; print(torch.cuda.device_count())")
 if [ "$NG" -ge 2 ]; then
   export HSA_ENABLE_IPC_MODE_LEGACY=0 NCCL_DEBUG=VERSION
+  # FIRST on a multi-GPU lease: the RCCL variants of the sharded tests -- tiny nets, and BASELINE configs[2] at full size walked along the reference's
+  # own run with one rank per GPU (tests/test_gpu_sharded.py::test_sharded_config3_walk_against_the_reference_run[nccl]: rccl ranks == GPUs, 72 collectives,
+  # rewards within 5e-8, every decidable decision equal, final image)
+  timeout -k 10 1500 python -m pytest tests/test_gpu_sharded.py -m gpu -q -k nccl -s > $O/final_pytest_rccl.log 2>&1 || { tail -30 $O/final_pytest_rccl.log; exit 1; }
+  tail -3 $O/final_pytest_rccl.log
   for n in 1 2 4 8; do
     [ "$n" -le "$NG" ] || continue
     python bench.py --gpus $n --steps 10 --warmup 3 $Q > $O/final_scale_n$n.json 2> $O/final_scale_n$n.err || exit 1
