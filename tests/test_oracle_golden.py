@@ -177,13 +177,20 @@ def test_fullsize_eps_greedy_n64_first_decision_matches_reference(golden_full, m
     assert int(got.argmax()) == int(golden_full['eg64_selected'][0]) == m['selected'][0]
 
 
-def test_config3_reference_run_golden_is_consistent_and_the_oracle_scores_its_final_image(golden_full, manifest_full, golden_c3, manifest_c3):
+@pytest.mark.parametrize('which', ['seed71', 'seed0'])
+def test_config3_reference_run_golden_is_consistent_and_the_oracle_scores_its_final_image(golden_full, manifest_full, request, which):
     """tests/golden/config3_golden.npz (the reference's own end-to-end run of BASELINE configs[2]; the GPU suite compares whole searches with
     it): 72 decisions x 64 rewards, `selected` = first argmax, the exact ties are where no churn noise is drawn (sigma > 50, < 0.05), the 8 995
     denoiser rows are counted below, the PNG is the quantised final state (edm/main.py:869), and the ORACLE's
     denoiser + scorer reproduce the reference's last denoiser call and final score from the stored inputs (one full-size row each)."""
     from helpers import full_weights
-    m, g = manifest_c3, golden_c3
+    # config3_golden.npz: the run at the seed that was scanned on the GPU for wide margins (71); config3_seed0_golden.npz: a second run at an unscanned seed
+    m, g = (request.getfixturevalue('manifest_c3'), request.getfixturevalue('golden_c3')) if which == 'seed71' else \
+        (request.getfixturevalue('manifest_c3_seed0'), request.getfixturevalue('golden_c3_seed0'))
+    assert m['seed'] == (71 if which == 'seed71' else 0)
+    if 'pivot_sum' in g.files:          # the noise the reference's own loop carried on after each decision (make_golden_config3.py reads it off the loop's state)
+        assert g['pivot_sum'].shape == (72,) and g['pivot_head'].shape == (72, 8) and len(m['pivot_sha256']) == 72 and len(set(m['pivot_sha256'])) == 72
+        assert m['checks'] == dict(carried_pivot_matches_one_candidate=True, carried_equals_argmax_of_recorded_rewards=True)
     rew, sel = g['rewards'], [int(v) for v in g['selected']]
     assert rew.shape == (72, 64) and rew.dtype == np.float32 and sel == m['selected'] == [int(r.argmax()) for r in rew]
     # rows (edm/main.py:749-860): per sigma step K candidate batches of N rows + the batch-1 step of the final pivot, two denoiser calls each
@@ -196,7 +203,8 @@ def test_config3_reference_run_golden_is_consistent_and_the_oracle_scores_its_fi
     for d in ties:
         assert np.all(rew[d] == rew[d][0]) and sel[d] == 0                      # identical candidates, first-max rule
     assert m['exact_ties'] == len(ties) and all(d < 8 or d >= 60 for d in ties)   # steps 0-1 (sigma 80, 57.6) and 15-17 (sigma < 0.05)
-    assert m['adm_imagenet64']['checksum'] == manifest_full['adm_imagenet64']['checksum']
+    a_, b_ = m['adm_imagenet64']['checksum'], manifest_full['adm_imagenet64']['checksum']
+    assert a_['numel'] == b_['numel'] and abs(a_['abs_sum'] - b_['abs_sum']) <= 1e-12 * b_['abs_sum']
     # the final state is the last call's output (x_next = x_hat + (0 - t) * (x_hat - D) / t), the PNG its quantisation
     D = g['last_D'][0].astype(np.float64)
     img = np.clip(D * 127.5 + 128, 0, 255).astype(np.uint8).transpose(1, 2, 0)
@@ -210,3 +218,30 @@ def test_config3_reference_run_golden_is_consistent_and_the_oracle_scores_its_fi
     sc = oscore.ImageNetOracle(oracle_cls_cfg(ccfg), csd)(torch.from_numpy(img.transpose(2, 0, 1)[None].copy()), lab, torch.zeros(1))
     print(f'oracle on the reference run\'s last step: max |D - D_ref| = {err:.2e}; final score {float(sc[0]):.6e} vs {float(g["final_score"][0]):.6e}')
     assert err < 2e-5 and abs(float(sc[0]) - float(g['final_score'][0])) < 5e-8
+
+
+def test_mcts_fullsize_reference_run_golden_and_the_oracle(manifest_full, golden_mcts_full):
+    """tests/golden/mcts_fullsize_golden.npz (the reference's own MCTS search at full network size, edm/main.py:405-713: N = 4, S = 16, three
+    sigma steps): internal consistency, and the ORACLE's MCTS on the same inputs -- every group's rewards, the child made root at every
+    timestep, the denoiser row count, the final state."""
+    from helpers import full_weights
+    from diffusion_tts_amd.hashing import seed0_scale
+    g, m = golden_mcts_full
+    assert g['rewards'].shape == (3, 16) and [int(v) for v in g['selected']] == m['selected'] and m['net_rows'] == 52 and m['scorer_calls'] == 4
+    assert m['chosen'][0]['n_equal_in_value'] == 4 and m['chosen'][1]['n_equal_in_value'] == 1      # sigma 80 > S_max: no churn, the four children of the root are equal in value
+    img = np.clip(g['x_final'][0] * 127.5 + 128, 0, 255).astype(np.uint8).transpose(1, 2, 0)
+    assert np.array_equal(img, g['image'])
+    torch.set_num_threads(8)
+    cfg, sd = full_weights(manifest_full, 'adm_imagenet64')
+    ccfg, csd = full_weights(manifest_full, 'cls_imagenet64')
+    lat = torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(m['latent_seed']))
+    assert np.array_equal(lat.numpy(), g['latents'])
+    lab = torch.eye(1000)[torch.tensor([m['label']])]
+    onet = oracle_net(cfg, sd)
+    np.random.seed(m['numpy_seed'])
+    o = osamp.search(onet, lat, lab, method='mcts', params=dict(scorer=oscore.ImageNetOracle(oracle_cls_cfg(ccfg), csd), **m['params']), scale_fn=seed0_scale,
+                     seed=m['seed'], num_steps=m['num_steps'], **m['S'])
+    errs = [float(np.abs(o['rewards'][j].reshape(-1).numpy().astype(np.float64) - g['rewards'][j].astype(np.float64)).max()) for j in range(3)]
+    x_err = float((o['x'] - T(g['x_final'])).abs().max())
+    print(f'oracle MCTS at full size vs the reference run: reward errs {errs}, children {[int(v) for v in o["selected"]]} (reference {m["selected"]}), rows {onet.evals}, max |x - x_ref| {x_err:.2e}')
+    assert max(errs) < 5e-8 and [int(v) for v in o['selected']] == m['selected'] and onet.evals == m['net_rows'] and x_err < 1e-3
