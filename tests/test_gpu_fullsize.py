@@ -652,6 +652,8 @@ def test_config3_in_pieces_of_8_candidates_against_the_reference_run(golden_full
 def test_config3_second_seed_walk_against_the_reference_run(golden_full, manifest_full, golden_c3_seed0, manifest_c3_seed0, chunk):
     """A SECOND run of configs[2] by the reference, at a seed (0) that was NOT scanned on the GPU beforehand (seed 71 of config3_golden.npz was
     picked for its wide top-2 margins, tools/seed_scan.py).  On an unscanned seed some decisions are decided by less than fp32 noise, so a
-    free-running comparison is a coin flip there; the forced-selection walk is seed-agnostic and is what is asserted: all 72 x 64 rewards
+    free-running comparison is a coin flip there (it is run and reported, and may differ only at such a decision); the forced-selection walk is seed-agnostic and is what is asserted: all 72 x 64 rewards
     within 5e-8, every decidable decision equal, exact ties exact, the carried pivots, the row count, the final state and PNG."""
-    _config3_against_reference_run(golden_full, manifest_full, golden_c3_seed0, manifest_c3_seed0, X3, chunk=chunk, free_running=False)
+    # (free-running too, at the whole batch: reported; a differing selection is accepted only where the reference decided by less than 4x the reward error --
+    #  on this seed four decisions are that close -- and the end of the search stays bounded)
+    _config3_against_reference_run(golden_full, manifest_full, golden_c3_seed0, manifest_c3_seed0, X3, chunk=chunk, free_running=chunk is None)
