@@ -242,6 +242,10 @@ def test_sharded_config3_walk_against_the_reference_run(backend):
         pytest.skip('tests/golden/config3_golden.npz not generated')
     if backend == 'nccl' and torch.cuda.device_count() < 2:
         pytest.skip('the RCCL variant needs 2 GPUs')
+    if backend == 'gloo' and os.environ.get('DTS_TEST_SHARDED_FULLSIZE', '0') != '1':
+        # ~95 s on a one-GPU box (two processes, two full-size network pairs, a 72-decision search on a shared GPU): part of the round's evidence run
+        # (tools/final_run.sh sets the variable), not of every default `pytest -m gpu`; the one-GPU chunked walk of tests/test_gpu_fullsize.py always runs
+        pytest.skip('set DTS_TEST_SHARDED_FULLSIZE=1 for the two-rank gloo variant (tools/final_run.sh does)')
     world = 2 if backend == 'gloo' else min(8, 1 << (torch.cuda.device_count().bit_length() - 1))
     chunk = None if world == 8 else 8
     g = np.load(os.path.join(gd, 'config3_golden.npz'))

@@ -8,7 +8,7 @@
 #   `dist_backend == "nccl"` in every line, N = 1, 2, 4, 8 back to back.
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; rm -rf $O/final_*
-timeout -k 10 900 python -m pytest tests/ -m gpu -q --timeout 900 > $O/final_pytest.log 2>&1 || { tail -20 $O/final_pytest.log; exit 1; }
+DTS_TEST_SHARDED_FULLSIZE=1 timeout -k 10 1100 python -m pytest tests/ -m gpu -q --timeout 900 --durations=12 > $O/final_pytest.log 2>&1 || { tail -20 $O/final_pytest.log; exit 1; }
 tail -2 $O/final_pytest.log
 python bench.py --steps 10 --warmup 3 --conv-table --conv-sequence $O/final_conv_sequence.json > $O/final_bench.json 2> $O/final_bench.err || { tail -5 $O/final_bench.err; exit 1; }
 Q="--no-cpu-baseline --no-e2e --no-parity --no-subrecords"
