@@ -145,6 +145,52 @@ def test_baseline_config2_ddpmpp_rejection_full_trajectories():
         assert (o['x'] - h['x'].cpu()).abs().max().item() < 1e-3
 
 
+@pytest.mark.parametrize('dtype', [X3, torch.float32])
+def test_baseline_configs_1_and_2_against_the_reference_runs(manifest_full, dtype):
+    """BASELINE.json configs[0] (DDPM++ CIFAR-32, NAIVE, 35 rows) and configs[1] (REJECTION N = 16, brightness, 560 rows) at full size against THE
+    REFERENCE'S OWN RUNS of them (tests/golden/make_golden_configs01.py: edm/main.py generate_image_grid on the CPU; no oracle in between): row counts,
+    the final state within 1e-3 (north_star), the uint8 image within 1 LSB, and for the rejection step the 16 rewards and the trajectory the
+    reference kept (read off its final image; its top-2 reward gap is 4.3e-4)."""
+    import json
+    import os
+    from conftest import ROOT
+    from helpers import full_weights
+    from diffusion_tts_amd import sampler as sm, scorers as S
+    from diffusion_tts_amd.hashing import seed0_scale
+    from diffusion_tts_amd.networks import EDMPrecond
+    gp = os.path.join(ROOT, 'tests', 'golden', 'configs01_golden.npz')
+    if not os.path.exists(gp):
+        pytest.skip('tests/golden/configs01_golden.npz not generated')
+    g = np.load(gp)
+    with open(os.path.join(ROOT, 'tests', 'golden', 'configs01_manifest.json')) as f:
+        m = json.load(f)
+    cfg, sd = full_weights(manifest_full, 'ddpmpp_cifar10')
+    net = EDMPrecond(cfg, sd, device=DEV, dtype=dtype)
+    kw = dict(seed=m['seed'], num_steps=m['num_steps'], gridw=1, gridh=1, device=torch.device(DEV), scale_fn=seed0_scale, compute_dtype=dtype, verbose=False, **m['S'])
+
+    def image_ok(h, ref):
+        diff = np.abs(h['image'][0].permute(1, 2, 0).numpy().astype(np.int32) - ref.astype(np.int32))
+        return diff.max() <= 1 and (diff > 0).mean() < 0.005
+    lat = torch.randn(1, 3, 32, 32, generator=torch.Generator().manual_seed(m['naive']['latent_seed']))
+    assert np.array_equal(lat.numpy(), g['naive_latents'])
+    h = sm.generate_image_grid(net, None, lat, torch.eye(10)[torch.tensor([m['naive']['label']])], sampling_method=sm.SamplingMethod.NAIVE,
+                               sampling_params=dict(scorer=S.BrightnessScorer()), **kw)
+    e0 = float((h['x'].cpu() - torch.from_numpy(g['naive_x_final'])).abs().max())
+    assert h['net_rows'] == m['naive']['net_rows'] == 35 and e0 < 1e-3 and image_ok(h, g['naive_image'])
+    assert abs(float(h['final_scores'][0]) - float(g['naive_final_score'][0])) < 5e-5
+    lat = torch.randn(1, 3, 32, 32, generator=torch.Generator().manual_seed(m['rejection']['latent_seed']))
+    assert np.array_equal(lat.numpy(), g['rej_latents'])
+    h = sm.generate_image_grid(net, None, lat, torch.eye(10)[torch.tensor([m['rejection']['label']])], sampling_method=sm.SamplingMethod.REJECTION_SAMPLING,
+                               sampling_params=dict(scorer=S.BrightnessScorer(), **m['rejection']['params']), **kw)
+    rew = h['rewards'][0].reshape(-1).numpy()
+    e_r = float(np.abs(rew - g['rej_rewards']).max())
+    e1 = float((h['x'].cpu() - torch.from_numpy(g['rej_x_final'])).abs().max())
+    print(f'configs[0] / [1] vs the reference runs, {dtype}: naive max |x - x_ref| {e0:.2e}; rejection reward err {e_r:.2e} (top-2 gap {m["rejection"]["top2_gap"]:.1e}), '
+          f'kept {int(h["selected"][0][0])} (reference {m["rejection"]["kept"]}), max |x - x_ref| {e1:.2e}')
+    assert h['net_rows'] == m['rejection']['net_rows'] == 560 and e_r < 5e-5 and m['rejection']['top2_gap'] > 4 * e_r
+    assert int(h['selected'][0][0]) == m['rejection']['kept'] == int(g['rej_kept'][0]) and e1 < 1e-3 and image_ok(h, g['rej_image'])
+
+
 def test_baseline_config3_adm64_eps_greedy_imagenet_scorer_reduced(adm):
     """BASELINE.json configs[2] (the headline workload: ADM ImageNet-64 + eps-greedy + the 64x64 classifier as scorer) at full
     network size, cut to 3 sigma-steps, N=4, K=1 so that the host oracle finishes in seconds: rewards to 5e-5, and wherever

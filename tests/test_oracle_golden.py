@@ -245,3 +245,32 @@ def test_mcts_fullsize_reference_run_golden_and_the_oracle(manifest_full, golden
     x_err = float((o['x'] - T(g['x_final'])).abs().max())
     print(f'oracle MCTS at full size vs the reference run: reward errs {errs}, children {[int(v) for v in o["selected"]]} (reference {m["selected"]}), rows {onet.evals}, max |x - x_ref| {x_err:.2e}')
     assert max(errs) < 5e-8 and [int(v) for v in o['selected']] == m['selected'] and onet.evals == m['net_rows'] and x_err < 1e-3
+
+
+def test_configs01_reference_runs_golden_and_the_oracle(manifest_full):
+    """tests/golden/configs01_golden.npz (the reference's own runs of BASELINE configs[0] and [1] at full DDPM++ CIFAR-32 size): internal consistency
+    (images = the quantised final states, the kept rejection trajectory = the argmax of the 16 recorded rewards), and the ORACLE's naive sampler on
+    configs[0] (35 full-size rows) reproduces the reference's final state."""
+    import json
+    import os
+    from conftest import ROOT
+    from helpers import full_weights
+    gp = os.path.join(ROOT, 'tests', 'golden', 'configs01_golden.npz')
+    if not os.path.exists(gp):
+        pytest.skip('tests/golden/configs01_golden.npz not generated')
+    g = np.load(gp)
+    with open(os.path.join(ROOT, 'tests', 'golden', 'configs01_manifest.json')) as f:
+        m = json.load(f)
+    for tag in ('naive', 'rej'):
+        img = np.clip(g[f'{tag}_x_final'][0] * 127.5 + 128, 0, 255).astype(np.uint8).transpose(1, 2, 0)
+        assert np.array_equal(img, g[f'{tag}_image'])
+    assert m['rejection']['kept'] == m['rejection']['argmax_of_rewards'] == int(g['rej_rewards'].argmax()) == int(g['rej_kept'][0]) and m['rejection']['rows_with_that_image'] == 1
+    assert m['naive']['net_rows'] == 35 and m['rejection']['net_rows'] == 16 * 35
+    torch.set_num_threads(8)
+    cfg, sd = full_weights(manifest_full, 'ddpmpp_cifar10')
+    lat = torch.randn(1, 3, 32, 32, generator=torch.Generator().manual_seed(m['naive']['latent_seed']))
+    o = osamp.search(oracle_net(cfg, sd), lat, torch.eye(10)[torch.tensor([m['naive']['label']])], method='naive', params=dict(scorer=oscore.BrightnessOracle()),
+                     seed=m['seed'], num_steps=m['num_steps'], **m['S'])
+    err = float((o['x'] - T(g['naive_x_final'])).abs().max())
+    print(f'oracle naive sampler at full DDPM++-32 size vs the reference run: max |x - x_ref| = {err:.2e}')
+    assert err < 1e-4 and (o['image'].int() - T(g['naive_image']).permute(2, 0, 1)[None].int()).abs().max().item() <= 1
