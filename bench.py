@@ -240,10 +240,15 @@ def conv_roofline(a, run_once, reps, dtype_name, value_per_gpu, gflop_per_eval, 
         # which kernel the launcher picks (csrc/conv_igemm.hip conv_pick_pp via dts_conv_kernel): the names a kernel trace shows
         kern = ops.conv_kernel(x1, w, x2=kw.get('x2'), up=bool(kw.get('up')), residual=kw.get('residual'), gn_coef=kw.get('gn_coef'))
         fam = {6: 'conv_pp_kernel', 4: 'conv_pp_kernel/128'}.get(kern) or ('conv_igemm_kernel/3x3' if w.shape[1] == 3 else 'conv_igemm_kernel/1x1')
-        rec.append((2.0 * n_ * ho * wo * co * w.shape[1] * w.shape[2] * w.shape[3], e0, e1,
+        kdim = w.shape[1] * w.shape[2] * w.shape[3]
+        sk = kw.get('skip')
+        if sk is not None:                  # the block's 1x1 skip convolution folded into this launch: its K steps and operands count here
+            kdim += sk[0].shape[3]
+            alg += es * sk[0].numel() + sk[1].packed.numel() * 2
+        rec.append((2.0 * n_ * ho * wo * co * kdim, e0, e1,
                     (tuple(x1.shape), tuple(w.shape), 'x2' if kw.get('x2') is not None else '', 'up' if kw.get('up') else '',
                      'res' if kw.get('residual') is not None else '', 'bnc' if kw.get('bias_nc') is not None else '',
-                     'stats' if kw.get('gn_stats') else ''), alg, fam))
+                     'stats' if kw.get('gn_stats') else '') + ((f'skip{sk[0].shape[3]}' + ('up' if sk[2] else ''),) if sk is not None else ()), alg, fam))
         return out
     ops.conv2d = timed_conv
     was = [c.enabled for c in extra_caches]

@@ -22,7 +22,8 @@ class ConvArgs(C.Structure):
                 ('n', C.c_int32), ('hin', C.c_int32), ('win', C.c_int32), ('cout', C.c_int32),
                 ('ksize', C.c_int32), ('up', C.c_int32), ('out_scale', C.c_float), ('dtype', C.c_int32),
                 ('workspace', _p), ('workspace_bytes', C.c_int64), ('stats_out', _p), ('stats_written', C.c_int32),
-                ('ev_start', _p), ('ev_stop', _p), ('gn_coef', _p), ('gn_silu', C.c_int32), ('acc_scale', C.c_float), ('out_split2', C.c_int32)]
+                ('ev_start', _p), ('ev_stop', _p), ('gn_coef', _p), ('gn_silu', C.c_int32), ('acc_scale', C.c_float), ('out_split2', C.c_int32),
+                ('skip_c', C.c_int32), ('skip_x', _p), ('skip_w', _p), ('skip_acc_scale', C.c_float), ('skip_up', C.c_int32)]
 
 
 # name -> argtypes (every function returns int status except the three noted below)
@@ -67,10 +68,10 @@ SIGNATURES = {
     'dts_cfg_combine': [_p, _p, _f, _p, _i, _i64, _p],
     'dts_ddim_candidates': [_p, _p, _p, _p, _p, _i, _f, _f, _f, _i, _i64, _p],
 }
-OTHER = {'dts_version': ([], _i), 'dts_conv_fuses_gn': ([C.POINTER(ConvArgs)], _i), 'dts_conv_kernel': ([C.POINTER(ConvArgs)], _i), 'dts_set_tuning': ([_i, _i], _i), 'dts_get_tuning': ([_i], _i), 'dts_last_error': ([], C.c_char_p), 'dts_gn_ws_floats': ([_i, _i], _i64)}
+OTHER = {'dts_version': ([], _i), 'dts_conv_fuses_gn': ([C.POINTER(ConvArgs)], _i), 'dts_conv_kernel': ([C.POINTER(ConvArgs)], _i), 'dts_conv_folds_skip': ([C.POINTER(ConvArgs)], _i), 'dts_set_tuning': ([_i, _i], _i), 'dts_get_tuning': ([_i], _i), 'dts_last_error': ([], C.c_char_p), 'dts_gn_ws_floats': ([_i, _i], _i64)}
 
 _lib = None
-ABI_VERSION = 110              # include/dts.h DTS_ABI_VERSION this binding was written against (ConvArgs = 184 bytes)
+ABI_VERSION = 111              # include/dts.h DTS_ABI_VERSION this binding was written against (ConvArgs = 208 bytes)
 
 
 def load():
@@ -89,7 +90,7 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes, fn.restype = argt, rest
     got = lib.dts_version()
-    if got != ABI_VERSION or C.sizeof(ConvArgs) != 184:
+    if got != ABI_VERSION or C.sizeof(ConvArgs) != 208:
         raise RuntimeError(f'{LIB_PATH} has ABI version {got}, this binding needs {ABI_VERSION}: rebuild with `python -m diffusion_tts_amd.build --force`')
     _lib = lib
     return lib
@@ -101,7 +102,7 @@ def check(status, what=''):
         raise RuntimeError(f'libdts_hip {what} failed ({status}): {msg}')
 
 
-KNOBS = {'att_xcd': 0, 'att_qt': 1, 'conv_tile': 2, 'conv_splits': 3, 'conv_variant': 4, 'gn_fuse': 5, 'att_db': 6, 'conv_stages': 7, 'conv_waves': 8, 'conv_half_round': 9, 'conv_epi32': 10}
+KNOBS = {'att_xcd': 0, 'att_qt': 1, 'conv_tile': 2, 'conv_splits': 3, 'conv_variant': 4, 'gn_fuse': 5, 'att_db': 6, 'conv_stages': 7, 'conv_waves': 8, 'conv_half_round': 9, 'conv_epi32': 10, 'conv_skip_fold': 11}
 
 
 def set_tuning(name, value):

@@ -64,6 +64,7 @@ class EncoderUNetModel:
                 P.sw = P.sb = None
                 if L.cin != L.cout:
                     P.sw, P.sb = ops.pack_conv_weight(f(sd[f'{p}.skip_connection.weight']), dt), f(sd[f'{p}.skip_connection.bias'])
+                    P.cb1_skip = (P.cb1 + P.sb).contiguous()         # conv1's bias with the skip convolution folded in (ops.conv_folds_skip)
             else:
                 heads = L.cin // hc
                 perm = _qkv_perm_legacy(heads, hc).to(self.device)
@@ -97,6 +98,8 @@ class EncoderUNetModel:
         h = ops.conv2d(h, P.w0, P.cb0, gn_stats=True)
         ss = emb_all[:, P.off:P.off + 2 * L.cout]
         h = ops.group_norm(h, 32, 1e-5, P.g1, P.b1, scale_shift=ss, silu=True, split_out=self.x3)
+        if raw and ops.conv_folds_skip(h, P.w1, (x, P.sw, False)):          # the 1x1 skip convolution as a second K loop of conv1's launch
+            return ops.conv2d(h, P.w1, P.cb1_skip, skip=(x, P.sw, False), gn_stats=True)
         sk = x if P.sw is None else ops.conv2d(x, P.sw, P.sb)
         return ops.conv2d(h, P.w1, P.cb1, residual=sk, gn_stats=True)
 

@@ -24,7 +24,7 @@
 #include <hip/hip_ext.h>
 #include <type_traits>
 
-static_assert(sizeof(dts_conv_args) == 184, "dts_conv_args layout changed: bump DTS_ABI_VERSION and update the bindings (_lib.py ConvArgs)");
+static_assert(sizeof(dts_conv_args) == 208, "dts_conv_args layout changed: bump DTS_ABI_VERSION and update the bindings (_lib.py ConvArgs)");
 
 namespace {
 
@@ -61,6 +61,10 @@ struct ConvP {
   const float* gn_coef;    // optional [n][cin][2] (a, b): GroupNorm of the INPUT applied on the staged halo tile (conv_pp_kernel only)
   int gn_silu;
   int epi_rows;            // f32 outputs: 1 = the row-layout epilogue (conv_epilogue_rows_f32), 0 = the accumulator-layout one (DTS_CONV_EPI32=0)
+  // split-precision ping-pong launches only: the block's 1x1 skip convolution as a second K loop (conv_pp_kernel<.., SK = true>)
+  const char* sk_x; const char* sk_w;      // split image of the block input [n][hout >> sk_up][wout >> sk_up][sk_c], packed weight [cout][sk_c]
+  int sk_c, sk_up;
+  float sk_ratio;          // acc_scale of the 3x3 weight / acc_scale of the skip weight (a power of two): the accumulators change units before the second loop
 };
 
 template <typename T> struct Mma;
@@ -1019,7 +1023,7 @@ __device__ __forceinline__ uint4 gn_act8(const uint4 v, const float (&ca)[8], co
 // inputs still give identical outputs (ties stay ties).
 // DBG != 0: timing-only diagnostic builds (outputs wrong by construction; tools/conv_bench.py conv_variant=11/21/41/51):
 //   1 = no LDS-DMA after the prologue, 2 = no MFMAs, 4 = every halo piece out of range, 5 = every A piece out of range
-template <typename T, int TAPS, int DBG = 0, bool GN = false, int MT = 6, typename OT = T>
+template <typename T, int TAPS, int DBG = 0, bool GN = false, int MT = 6, typename OT = T, bool SK = false>
 __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
   // MT = M tiles (of 16 couts) per wave: 6 -> 192-cout blocks (the EDM U-Net widths), 4 -> 128-cout blocks (classifier, SD VAE widths)
   static_assert(MT == 6 || MT == 4, "cout tile");
@@ -1399,6 +1403,89 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
 #undef PP_ADVANCE_A
 #undef PP_LOAD_COEF
 #undef PP_GN_PIECE
+  if constexpr (SK) {
+    // ---- FOLDED 1x1 SKIP CONVOLUTION (split precision, splits == 1; dts_conv_args.skip_*): out = conv3x3(h) + conv1x1(block input), one
+    // epilogue.  A second, plain K loop over the skip operand's 32-channel steps: the whole LDS is free now (the barrier above: every fragment of
+    // the last 3x3 tile is in registers, every LDS-DMA piece has landed), two stages of [BM weight rows | the tile's 256 pixel rows] x 128 bytes,
+    // one barrier per step.  The waves keep their accumulator tiles.  The two wave groups of a SIMD pair issue the next step's pieces on
+    // OPPOSITE sides of their MFMAs (group 0 before, group 1 after), so one wave's LDS-DMA issue sits under its partner's matrix work.
+    // The accumulators change units first: the two packed weights carry different powers of two (exact: a power-of-two ratio).
+    static_assert(X3I, "skip fold: split precision only");
+    const int sC = kp.sk_c, nks = sC / BKE, su = kp.sk_up ? 1 : 0, Hs = H >> su, Ws = W >> su;
+    const float ratio = kp.sk_ratio;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] *= ratio;
+    constexpr int S_A = BM * 128, S_STAGE = S_A + BN * 128;
+    static_assert(2 * S_STAGE <= H_OFF + 2 * H_BUF, "skip fold: two stages fit the kernel's LDS");
+    // (readfirstlane: behind the loop hipcc keeps these uniform values in vector registers, which the LDS-DMA statement cannot take)
+    dts_i32x4 rs_sw = make_rsrc(kp.sk_w, (uint32_t)((size_t)kp.cout * sC * ES));
+    dts_i32x4 rs_sx = make_rsrc(kp.sk_x, (uint32_t)((size_t)kp.n * Hs * Ws * sC * ES));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { rs_sw[e] = __builtin_amdgcn_readfirstlane(rs_sw[e]); rs_sx[e] = __builtin_amdgcn_readfirstlane(rs_sx[e]); }
+    uint32_t savo[AJ], sbvo[4];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) savo[j] = (uint32_t)((cm0 + 8 * (w + 8 * j) + r0) * sC) * ES + schunk;       // weight rows: piece w + 8j of BM / 8
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                                                                             // pixel rows: piece w + 8j of 32
+      const int pl = 8 * (w + 8 * j) + r0, y = y0 + (pl >> 4), x = x0 + (pl & 15);
+      sbvo[j] = (uint32_t)(((img0 * Hs + (y >> su)) * Ws + (x >> su)) * sC) * ES + schunk;
+    }
+    const uint32_t sa_dst = lds_base + (8 * w) * 128, sb_dst = lds_base + S_A + (8 * w) * 128;
+#define SK_ISSUE(kt_, stage_)                                                                                  \
+    {                                                                                                         \
+      const uint32_t so_ = (uint32_t)(kt_) * 128u, d_ = (uint32_t)(stage_) * S_STAGE;                          \
+      _Pragma("unroll") for (int j = 0; j < AJ; ++j) bdma16(savo[j], rs_sw, so_, sa_dst + d_ + j * (64 * 128)); \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) bdma16(sbvo[j], rs_sx, so_, sb_dst + d_ + j * (64 * 128));  \
+    }
+    SK_ISSUE(0, 0);
+#pragma unroll 1
+    for (int kt = 0; kt < nks; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      const int stg = kt & 1;
+      const bool nxt = kt + 1 < nks;
+      if (grp == 0 && nxt) SK_ISSUE(kt + 1, stg ^ 1);
+      const char* sa = smem + stg * S_STAGE + (grp * GM) * 128;
+      const char* sb = smem + stg * S_STAGE + S_A;
+      uint4 fa[MT], fb[NT], ga[MT], gb[NT], fs[MT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int off = swz(wn * 64 + i * 16 + lrow, lq);
+        fb[i] = *reinterpret_cast<const uint4*>(sb + off);
+        gb[i] = *reinterpret_cast<const uint4*>(sb + (off ^ 64));
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int off = swz(i * 16 + lrow, lq);
+        fa[i] = *reinterpret_cast<const uint4*>(sa + off);
+        ga[i] = *reinterpret_cast<const uint4*>(sa + (off ^ 64));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < MT; ++i) fs[i] = f16x8_mul_2m11(fa[i]);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], fs[i], gb[j]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], ga[i], fb[j]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (grp == 1 && nxt) SK_ISSUE(kt + 1, stg ^ 1);
+    }
+#undef SK_ISSUE
+  }
   __syncthreads();
   DTS_STAMP(2);
 
@@ -1668,7 +1755,7 @@ int launch_conv(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, C
 }
 
 // ---- ping-pong launcher: one block per (192- or 128-cout tile, 256-pixel tile[, K split]); 512 threads, 154 KB (MT = 6) / 130 KB (MT = 4) of LDS
-template <typename T, int TAPS, int DBG = 0, bool GN = false, int MT = 6, typename OT = T>
+template <typename T, int TAPS, int DBG = 0, bool GN = false, int MT = 6, typename OT = T, bool SK = false>
 int launch_conv_pp(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes, ConvCall& call) {
   // 3x3 only: the kernel's TAPS == 1 form has a landing race with more than one channel chunk (see conv_pick_pp) and must not be launched
   static_assert(TAPS == 9, "conv_pp_kernel: only the 3x3 form is safe to launch");
@@ -1683,7 +1770,7 @@ int launch_conv_pp(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes
     const int nk = p.taps * (p.cin / BKE);
     int splits = 1;
     const int forced = dts_knob_get(DTS_KNOB_CONV_SPLITS);
-    if (ws != nullptr && nk >= 16 && !p.out_split2) {
+    if (ws != nullptr && nk >= 16 && !p.out_split2 && !SK) {      // (SK: the second K loop needs the complete accumulators; dts_conv_folds_skip only admits grids that would not split)
       if (forced > 0) splits = forced;
       else if (nblk < 192) {
         // One resident block per CU.  Splitting K fills idle CUs but pays a second pass over `splits` f32 slabs of P x cout, which for
@@ -1722,13 +1809,13 @@ int launch_conv_pp(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes
     static bool attr_done[DTS_MAX_DEVICES] = {};
     const int dev = current_device();
     if (!attr_done[dev]) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<T, TAPS, DBG, GN, MT, OT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pp_kernel<T, TAPS, DBG, GN, MT, OT, SK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_done[dev] = true;
     }
     if (call.ev_start != nullptr && call.ev_stop != nullptr)
-      hipExtLaunchKernelGGL((conv_pp_kernel<T, TAPS, DBG, GN, MT, OT>), dim3(nblk, splits), dim3(512), lds, st, call.ev_start, call.ev_stop, 0, q);
+      hipExtLaunchKernelGGL((conv_pp_kernel<T, TAPS, DBG, GN, MT, OT, SK>), dim3(nblk, splits), dim3(512), lds, st, call.ev_start, call.ev_stop, 0, q);
     else
-      hipLaunchKernelGGL((conv_pp_kernel<T, TAPS, DBG, GN, MT, OT>), dim3(nblk, splits), dim3(512), lds, st, q);
+      hipLaunchKernelGGL((conv_pp_kernel<T, TAPS, DBG, GN, MT, OT, SK>), dim3(nblk, splits), dim3(512), lds, st, q);
     DTS_CHECK_LAUNCH("dts_conv2d(ping-pong)");
     if (splits > 1) {
       if (stats_in_reduce) q.stats = stats_req;
@@ -1803,6 +1890,11 @@ int conv_dispatch(const ConvP& p, hipStream_t st, float* ws, long long ws_bytes,
   if (std::is_same<T, float>::value && tile == 192 && !f32_192) tile = (p.cout % 128 == 0) ? 128 : 64;
   const int pp = conv_pick_pp(std::is_same<T, float>::value, p, !std::is_same<T, OT>::value);
   if constexpr (!std::is_same<T, OT>::value) {       // split-precision mode: the two shipped ping-pong forms and the implicit-GEMM forms, no knob variants
+    if (p.sk_w != nullptr) {                         // dts_conv2d has checked dts_conv_folds_skip
+      if (pp == 6) return launch_conv_pp<T, 9, 0, false, 6, OT, true>(p, st, ws, ws_bytes, call);
+      if (pp == 4) return launch_conv_pp<T, 9, 0, false, 4, OT, true>(p, st, ws, ws_bytes, call);
+      return DTS_ERR_UNSUPPORTED;
+    }
     if (pp == 6) return launch_conv_pp<T, 9, 0, false, 6, OT>(p, st, ws, ws_bytes, call);
     if (pp == 4) return launch_conv_pp<T, 9, 0, false, 4, OT>(p, st, ws, ws_bytes, call);
     if (g_tile_override > 0 && p.cout % g_tile_override == 0) tile = g_tile_override;
@@ -1885,6 +1977,24 @@ extern "C" int dts_conv_fuses_gn(const dts_conv_args* a) {
   return (variant == 1 || blocks_pp >= 64) ? 1 : 0;              // with gn_coef the kernel choice does not depend on the residual
 }
 
+extern "C" int dts_conv_folds_skip(const dts_conv_args* a) {
+  if (a == nullptr || a->dtype != DTS_F16X3 || a->ksize != 3 || a->up || a->residual != nullptr || a->out_split2 || a->gn_coef != nullptr) return 0;
+  if (a->skip_c <= 0 || a->skip_c % 64 != 0 || a->n <= 0 || a->hin <= 0 || a->win <= 0 || a->cout <= 0) return 0;
+  if (dts_knob_get(DTS_KNOB_CONV_SKIP_FOLD) == 0 || dts_knob_get(DTS_KNOB_CONV_SPLITS) > 0) return 0;
+  if ((long long)a->n * a->hin * a->win >= (1ll << 30)) return 0;
+  if (a->skip_up && ((a->hin | a->win) & 1)) return 0;
+  ConvP p;
+  conv_shape_from_args(a, p);
+  const int mt = conv_pick_pp(false, p, true);
+  if (mt == 0) return 0;
+  const long long nblk = (long long)(p.cout / (32 * mt)) * ((p.P + 255) / 256);
+  // a grid below 192 blocks would take a K split (launch_conv_pp), which the fold excludes: there the separate 1x1 launch stays.  (Forced
+  // ping-pong, DTS_CONV_VARIANT=1: any grid folds, unsplit -- the tests' small shapes.)
+  if (nblk < 192 && dts_knob_get(DTS_KNOB_CONV_VARIANT) != 1) return 0;
+  const long long px = (long long)a->n * (a->hin >> (a->skip_up ? 1 : 0)) * (a->win >> (a->skip_up ? 1 : 0));
+  return (px * a->skip_c * 2 < (1ll << 31) && (long long)a->cout * a->skip_c * 2 < (1ll << 31)) ? 1 : 0;
+}
+
 extern "C" int dts_conv2d(dts_conv_args* a, dts_stream s) {
   DTS_CHECK_ARG(a != nullptr, "dts_conv2d: null args");
   DTS_CHECK_ARG(a->x1 && a->w && a->out, "dts_conv2d: null tensor");
@@ -1926,6 +2036,14 @@ extern "C" int dts_conv2d(dts_conv_args* a, dts_stream s) {
   }
   DTS_CHECK_ARG(a->gn_coef == nullptr || dts_conv_fuses_gn(a), "dts_conv2d: gn_coef given for a launch that cannot fuse the GroupNorm apply "
                 "(ask dts_conv_fuses_gn first)");
+  p.sk_x = p.sk_w = nullptr; p.sk_c = p.sk_up = 0; p.sk_ratio = 1.f;
+  if (a->skip_c != 0 || a->skip_w != nullptr || a->skip_x != nullptr) {
+    DTS_CHECK_ARG(a->skip_w != nullptr && a->skip_x != nullptr && dts_conv_folds_skip(a), "dts_conv2d: skip_* given for a launch that cannot fold the 1x1 "
+                  "skip convolution (ask dts_conv_folds_skip first)");
+    const float ss = a->skip_acc_scale == 0.f ? 1.f : a->skip_acc_scale;
+    p.sk_x = (const char*)a->skip_x; p.sk_w = (const char*)a->skip_w; p.sk_c = a->skip_c; p.sk_up = a->skip_up ? 1 : 0;
+    p.sk_ratio = p.acc_scale / ss; p.acc_scale = ss;
+  }
   p.stats = a->stats_out;
   DTS_CHECK_ARG(a->stats_out == nullptr || ((p.hout * p.wout) % 64 == 0 && (uintptr_t)a->stats_out % 16 == 0),
                 "dts_conv2d: strip statistics need hout*wout to be a multiple of 64 and a 16-byte aligned buffer");

@@ -51,6 +51,7 @@ enum dts_knob {
   DTS_KNOB_CONV_WAVES = 8,     // DTS_CONV_WAVES   4|8: waves per block of conv_igemm_kernel (default: 8 for grids of <= 256 blocks)
   DTS_KNOB_CONV_HALF_ROUND = 9,// DTS_CONV_HALF_ROUND 0 / 1: half-round grids of the 128-cout ping-pong form at >= 32x32 stay on that kernel / go to the implicit GEMM (A/B aid; default: implicit GEMM in the 16-bit modes, ping-pong in split precision)
   DTS_KNOB_CONV_EPI32 = 10,    // DTS_CONV_EPI32   0 | 1: f32 outputs leave through the accumulator-layout | the row-layout epilogue (default: row layout in the split-precision mode, accumulator layout in the f32 parity mode)
+  DTS_KNOB_CONV_SKIP_FOLD = 11,// DTS_CONV_SKIP_FOLD 0: dts_conv_folds_skip answers 0 (the 1x1 skip convolution stays its own launch; A/B aid)
   DTS_KNOB_COUNT = 16
 };
 int dts_knob_get(int knob);    // defined in elementwise.hip

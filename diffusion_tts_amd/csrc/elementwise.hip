@@ -21,7 +21,7 @@ static int g_knob[DTS_KNOB_COUNT];
 static bool g_knob_init = false;
 static const char* const g_knob_env[DTS_KNOB_COUNT] = {"DTS_ATT_XCD", "DTS_ATT_QT", "DTS_CONV_TILE", "DTS_CONV_SPLITS",
                                                        "DTS_CONV_VARIANT", "DTS_GN_FUSE", "DTS_ATT_DB", "DTS_CONV_STAGES", "DTS_CONV_WAVES",
-                                                       "DTS_CONV_HALF_ROUND", "DTS_CONV_EPI32"};
+                                                       "DTS_CONV_HALF_ROUND", "DTS_CONV_EPI32", "DTS_CONV_SKIP_FOLD"};
 static void knob_init() {
   if (g_knob_init) return;
   for (int i = 0; i < DTS_KNOB_COUNT; ++i) {

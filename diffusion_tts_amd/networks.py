@@ -106,6 +106,7 @@ class EDMPrecond:
             P.skip_w = P.skip_b = None
             if f'{n}.skip.weight' in sd:
                 P.skip_w, P.skip_b = ops.pack_conv_weight(f(g('skip.weight')), dt), f(g('skip.bias'))
+                P.cb1_skip = (P.cb1 + P.skip_b).contiguous()         # the bias of conv1 with the skip convolution folded in (ops.conv_folds_skip)
             if b.heads:
                 d = b.cout // b.heads
                 perm = _qkv_perm_edm(b.heads, d).to(dev)
@@ -193,7 +194,10 @@ class EDMPrecond:
             coef1 = ops.gn_coefficients(h, G(b.cout), self.eps, P.g1, P.b1, scale_shift=ss if self.adm else None)
         else:
             h = ops.group_norm(h, G(b.cout), self.eps, P.g1, P.b1, scale_shift=ss if self.adm else None, silu=True, split_out=self.x3)
-        if P.skip_w is not None and skip_src is not None:
+        if P.skip_w is not None and skip_src is not None and ops.conv_folds_skip(h, P.w1, (skip_src, P.skip_w, b.up)):
+            # split-precision mode: the 1x1 skip convolution is a second K loop of conv1's launch (no f32 skip tensor written and read back)
+            sk = None
+        elif P.skip_w is not None and skip_src is not None:
             sk = ops.conv2d(skip_src, P.skip_w, P.skip_b, up=b.up)
         elif P.skip_w is not None:
             src1, src2 = (ops.resample2x(x1, up=False), None) if b.down else (x1, x2)
@@ -202,8 +206,11 @@ class EDMPrecond:
             sk = ops.resample2x(x1, up=b.up)
         else:
             sk = x1
-        x = ops.conv2d(h, P.w1, P.cb1, residual=sk, out_scale=self.skip_scale, gn_stats=True,
-                       gn_coef=coef1 if fuse1 else None, gn_silu=True)
+        if sk is None:
+            x = ops.conv2d(h, P.w1, P.cb1_skip, skip=(skip_src, P.skip_w, b.up), out_scale=self.skip_scale, gn_stats=True)
+        else:
+            x = ops.conv2d(h, P.w1, P.cb1, residual=sk, out_scale=self.skip_scale, gn_stats=True,
+                           gn_coef=coef1 if fuse1 else None, gn_silu=True)
         if b.heads:
             n, hh, ww, c = x.shape
             hn = ops.group_norm(x, G(c), self.eps, P.g2, P.b2, silu=False, split_out=self.x3)

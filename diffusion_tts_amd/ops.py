@@ -209,9 +209,34 @@ def conv_fuses_gn(x1, w, *, x2=None, up=False):
     return bool(L.load().dts_conv_fuses_gn(C.byref(_conv_args(x1, w, x2, up))))
 
 
+def _skip_fields(a, skip, n, ho, wo, cout):
+    """dts_conv_args.skip_*: skip = (SplitAct of the block input, X3Weight of the 1x1 layer, up)"""
+    src, sw, sup = skip
+    if not isinstance(src, SplitAct) or not isinstance(sw, X3Weight):
+        raise ValueError('conv2d: skip = (SplitAct, X3Weight, up)')
+    sh = (n, ho // 2, wo // 2) if sup else (n, ho, wo)
+    if tuple(src.shape[:3]) != sh or tuple(sw.shape) != (cout, 1, 1, src.shape[3]):
+        raise ValueError(f'conv2d: skip source {tuple(src.shape)} / weight {tuple(sw.shape)} do not match an output of {(n, ho, wo, cout)} (up={bool(sup)})')
+    a.skip_c, a.skip_x, a.skip_w = src.data.shape[-1], _ptr(src.data, 'skip_x', torch.float16), _ptr(sw.packed, 'skip_w', torch.float16)
+    a.skip_acc_scale, a.skip_up = sw.acc_scale, int(bool(sup))
+
+
+def conv_folds_skip(x1, w, skip):
+    """True if conv2d(x1, w, bias, skip=skip) accumulates the block's 1x1 skip convolution inside this 3x3 launch (dts_conv_folds_skip:
+    split-precision mode, ping-pong kernel, a grid that needs no K split); skip = (SplitAct of the block input, its X3Weight, up)."""
+    if not isinstance(w, X3Weight) or skip is None or not isinstance(skip[0], SplitAct):
+        return False
+    a = _conv_args(x1, w, None, False)
+    a.c1, a.c2, a.dtype = 2 * a.c1, 0, L.DTS_F16X3
+    _skip_fields(a, skip, a.n, a.hin, a.win, a.cout)
+    return bool(L.load().dts_conv_folds_skip(C.byref(a)))
+
+
 def conv2d(x1, w, bias=None, *, x2=None, bias_nc=None, residual=None, up=False, out_scale=1.0, out=None, gn_stats=False,
-           timing_events=None, gn_coef=None, gn_silu=True, out_split2=False):
-    """timing_events=(start, stop): raw hipEvent_t handles attached to the conv kernel's own dispatch (measurement only).
+           timing_events=None, gn_coef=None, gn_silu=True, out_split2=False, skip=None):
+    """skip=(SplitAct, X3Weight, up): the block's 1x1 skip convolution of that operand accumulated by this launch (only where conv_folds_skip()
+    says so; `bias` is then the sum of the two layers' biases and there is no `residual`).
+    timing_events=(start, stop): raw hipEvent_t handles attached to the conv kernel's own dispatch (measurement only).
     gn_stats=True: the epilogue also emits the GroupNorm moments of the output (per 64-pixel strip and channel); they
     ride on the returned tensor as `out._gn_stats` (None when the launch could not produce them) and are consumed by
     group_norm(), which then skips its own pass over the tensor."""
@@ -258,6 +283,10 @@ def conv2d(x1, w, bias=None, *, x2=None, bias_nc=None, residual=None, up=False, 
         a.stats_out = st.data_ptr()
     if timing_events is not None:
         a.ev_start, a.ev_stop = timing_events
+    if skip is not None:
+        if not x3 or residual is not None or up:
+            raise ValueError('conv2d: skip= is the split-precision mode\'s, without residual / upsample')
+        _skip_fields(a, skip, n, ho, wo, cout)
     if gn_coef is not None:       # GroupNorm (+SiLU) of the input applied on the staged tile: only where conv_fuses_gn() says so
         if tuple(gn_coef.shape) != (n, c1 + c2, 2):
             raise ValueError(f'conv2d: gn_coef shape {tuple(gn_coef.shape)} != {(n, c1 + c2, 2)}')

@@ -42,11 +42,12 @@ enum dts_dtype { DTS_F32 = 0, DTS_BF16 = 1, DTS_F16 = 2,
                  DTS_F16X3 = 3 };
 enum dts_status { DTS_OK = 0, DTS_ERR_ARG = -1, DTS_ERR_LAUNCH = -2, DTS_ERR_UNSUPPORTED = -3 };
 
-#define DTS_ABI_VERSION 110        /* bumped with every change of a signature or of dts_conv_args (101: ev_start/ev_stop; 102: tuning knobs; 103: dts_cosine_rows; 104: dts_nchw_to_nhwc_pad,
+#define DTS_ABI_VERSION 111        /* bumped with every change of a signature or of dts_conv_args (101: ev_start/ev_stop; 102: tuning knobs; 103: dts_cosine_rows; 104: dts_nchw_to_nhwc_pad,
                                      105: dts_conv_args.gn_coef / gn_silu, dts_conv_fuses_gn;
                                      head dim 512 in dts_attention; 106: dts_conv_kernel, 128-cout ping-pong blocks; 107: dts_resample_u8, dts_lut_u8_f32; 108: DTS_F16X3, dts_conv_args.acc_scale, dts_split3_f16, dts_gn_apply_x3, dts_split2_f16, dts_attention_x3;
                                      109: dts_candidate_noise_sd; the DTS_F16X3 operand images are 2*C wide, interleaved per 32 channels; dts_gn_apply_x3 raw_out;
-                                     110: dts_candidate_noise_sd takes the three scalars of the reference's product separately (scale [n][3])) */
+                                     110: dts_candidate_noise_sd takes the three scalars of the reference's product separately (scale [n][3]);
+                                     111: dts_conv_args.skip_* (a block's 1x1 skip convolution folded into its second 3x3), dts_conv_folds_skip) */
 int dts_version(void);            /* == DTS_ABI_VERSION of the build; a binding must refuse any other value */
 const char* dts_last_error(void);
 /* Tuning knobs (measurement aid; a knob only selects between kernels / block orders / ring depths that give correct results -- the
@@ -100,10 +101,21 @@ typedef struct dts_conv_args {
                                      two the packed split-precision weights carry */
   int32_t out_split2;             /* DTS_F16X3 only: 1 = `out` is f16 [n][hout][wout][2*cout] = hi(cout) | lo(cout) of the result * 2^6 per pixel, saturating (the
                                      image dts_split2_f16 would make of it: the qkv projection feeding dts_attention_x3) instead of f32 [..][cout] */
+  /* DTS_F16X3 only: the UNetBlock's 1x1 skip convolution (networks.py:164,177: x = conv1(..) + skip(orig)) accumulated by the SAME launch, as a
+     second K loop over the block input behind the 3x3 taps: out = ((conv + skip_conv) + bias) * out_scale with `bias` = the two layers' biases
+     added by the caller and no `residual`.  Only launches for which dts_conv_folds_skip() returns 1 accept it. */
+  int32_t skip_c;                 /* f16 elements per pixel of skip_x (= 2 x the skip conv's input channels), a multiple of 64; 0 = no fold */
+  const void* skip_x;             /* split image of the block input, f16 [n][hout >> skip_up][wout >> skip_up][skip_c] */
+  const void* skip_w;             /* the 1x1 layer's packed split-precision weight [cout][skip_c] */
+  float skip_acc_scale;           /* that weight's power of two (0 = 1), like acc_scale */
+  int32_t skip_up;                /* 1: skip_x is at half the output resolution (the nearest-2x upsample of networks.py:82-83 fused into the gather) */
 } dts_conv_args;
 /* 1 if dts_conv2d would apply a->gn_coef inside the conv for this shape / dtype (3x3, cout % 192 == 0, 16-bit, square power-of-two
  * images >= 16, whole 256-pixel tiles, no fused upsample), else 0: the caller then runs dts_gn_apply first. */
 int dts_conv_fuses_gn(const dts_conv_args* a);
+/* 1 if dts_conv2d accepts a->skip_* for this launch (DTS_F16X3, 3x3 on the ping-pong kernel with a grid that needs no K split, no residual /
+ * out_split2 / upsample of x1), else 0: the caller then runs the 1x1 layer as its own launch and passes its output as `residual`. */
+int dts_conv_folds_skip(const dts_conv_args* a);
 /* which kernel dts_conv2d takes for these arguments (shape, dtype, residual / gn_coef presence; tuning knobs included): 0 = the 4-wave
  * implicit-GEMM kernel, 6 / 4 = the 8-wave ping-pong / halo kernel with 192- / 128-cout blocks, -1 = invalid arguments.  Measurement aid:
  * bench.py attributes its per-launch times and algorithmic bytes to the kernel name a trace will show. */

@@ -161,6 +161,70 @@ def test_conv2d_split_precision(ops, case):
         assert torch.allclose(out._gn_stats, out32._gn_stats, rtol=1e-4, atol=1e-4 * max(1.0, scale) ** 2)
 
 
+@pytest.mark.parametrize('case', ['192_full_grid', '384_up', '576_16x16', '128_blocks', 'forced_small', 'scales_apart'])
+def test_conv2d_folds_the_skip_convolution(ops, case):
+    """Split-precision mode: a UNetBlock's 1x1 skip convolution (networks.py:164,177: x = (conv1(h) + skip(orig)) * skip_scale) accumulated by
+    conv1's OWN launch -- a second K loop of the ping-pong kernel over the block input's operand image (dts_conv_args.skip_*) -- against the two
+    launches it replaces (1x1 conv, then the 3x3 with that output as `residual`) and against the f64 reference: both block sizes of the kernel,
+    a skip operand at half the resolution (decoder up blocks), a full-chip grid and a forced small one, packed weights whose powers of two are
+    ~2^9 apart (the accumulators change units between the loops).  Where the launcher would split K the query must answer no."""
+    from diffusion_tts_amd import _lib
+    gen = g(11)
+    n, hw, c, cs, cout, up, forced, wsc = 12, 64, 192, 384, 192, False, False, 1.0
+    if case == '384_up':
+        n, hw, c, cs, cout, up = 24, 32, 384, 192, 384, True
+    if case == '576_16x16':
+        n, hw, c, cs, cout, up = 64, 16, 576, 768, 576, True
+    if case == '128_blocks':
+        n, hw, c, cs, cout = 24, 32, 256, 128, 256
+    if case in ('forced_small', 'scales_apart'):
+        n, hw, c, cs, cout, forced = 2, 32, 192, 64, 192, True
+    if case == 'scales_apart':
+        wsc = 2.0 ** -12 * 1.37
+    hs = hw // 2 if up else hw
+    h = torch.randn(n, c, hw, hw, generator=gen)
+    src = torch.randn(n, cs, hs, hs, generator=gen)
+    w1 = torch.randn(cout, c, 3, 3, generator=gen) / math.sqrt(c * 9)
+    ws = torch.randn(cout, cs, 1, 1, generator=gen) / math.sqrt(cs) * wsc
+    b1, bs = torch.randn(cout, generator=gen), torch.randn(cout, generator=gen)
+    srcd = src.double()
+    ref = (F.conv2d(h.double(), w1.double(), b1.double(), padding=1) +
+           F.conv2d(F.interpolate(srcd, scale_factor=2, mode='nearest') if up else srcd, ws.double(), bs.double())) * 0.70710678
+    hd = ops.SplitAct(ops.split3_f16(to_nhwc(ops, h, torch.float32)), c)
+    sd_ = ops.SplitAct(ops.split3_f16(to_nhwc(ops, src, torch.float32)), cs)
+    w1p, wsp = ops.pack_conv_weight(w1.to(DEV), ops.F16X3), ops.pack_conv_weight(ws.to(DEV), ops.F16X3)
+    if case == 'scales_apart':
+        assert w1p.acc_scale / wsp.acc_scale >= 2.0 ** 7
+    skip = (sd_, wsp, up)
+    if forced:
+        assert not ops.conv_folds_skip(hd, w1p, skip), 'a grid that would split K must not fold'
+        with pytest.raises(Exception, match='cannot fold'):
+            ops.conv2d(hd, w1p, (b1 + bs).to(DEV), skip=skip)
+        _lib.set_tuning('conv_variant', 1)
+    try:
+        assert ops.conv_folds_skip(hd, w1p, skip), case
+        folded = ops.conv2d(hd, w1p, (b1 + bs).to(DEV), skip=skip, out_scale=0.70710678, gn_stats=True)
+        again = ops.conv2d(hd, w1p, (b1 + bs).to(DEV), skip=skip, out_scale=0.70710678, gn_stats=True)
+        _lib.set_tuning('conv_skip_fold', 0)
+        assert not ops.conv_folds_skip(hd, w1p, skip)
+        sk = ops.conv2d(sd_, wsp, bs.to(DEV), up=up)
+        two = ops.conv2d(hd, w1p, b1.to(DEV), residual=sk, out_scale=0.70710678, gn_stats=True)
+    finally:
+        _lib.set_tuning('conv_variant', -1)
+        _lib.set_tuning('conv_skip_fold', -1)
+    assert torch.equal(folded, again)                          # fixed summation order
+    got, got2 = from_nhwc(ops, folded).double(), from_nhwc(ops, two).double()
+    scale = float(ref.abs().max())
+    e1, e2 = float((got - ref).abs().max()) / scale, float((got2 - ref).abs().max()) / scale
+    print(f'skip fold {case}: rel err folded {e1:.2e}, two launches {e2:.2e}')
+    # (the forced small grids: the two-launch conv1 takes a K split there, whose shorter f32 sums sit ~3x closer to the f64 reference)
+    assert e1 < 3e-6 and e1 < 4 * max(e2, 2e-7), (case, e1, e2)
+    # GroupNorm moments of the output: per image (which 64 pixels make a strip differs between the kernels: patch rows / consecutive pixels)
+    assert folded._gn_stats is not None and two._gn_stats is not None
+    per_image = lambda st: st.view(n, -1, cout, 2).sum(1)
+    assert torch.allclose(per_image(folded._gn_stats), per_image(two._gn_stats), rtol=1e-4, atol=1e-3 * max(1.0, scale) ** 2)
+
+
 def test_split_images_saturate_instead_of_poisoning(ops):
     """an activation beyond the f16 range (|x| >= 65520; |qkv| >= 1024 for the attention image, which carries 2^6) used to become
     hi = inf, lo = x - inf = NaN in the operand image and from there NaN in every output the element touches.  The images saturate at the
