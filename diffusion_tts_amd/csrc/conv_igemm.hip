@@ -1406,19 +1406,20 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
   if constexpr (SK) {
     // ---- FOLDED 1x1 SKIP CONVOLUTION (split precision, splits == 1; dts_conv_args.skip_*): out = conv3x3(h) + conv1x1(block input), one
     // epilogue.  A second, plain K loop over the skip operand's 32-channel steps: the whole LDS is free now (the barrier above: every fragment of
-    // the last 3x3 tile is in registers, every LDS-DMA piece has landed), two stages of [BM weight rows | the tile's 256 pixel rows] x 128 bytes,
-    // one barrier per step.  The waves keep their accumulator tiles.  The two wave groups of a SIMD pair issue the next step's pieces on
-    // OPPOSITE sides of their MFMAs (group 0 before, group 1 after), so one wave's LDS-DMA issue sits under its partner's matrix work.
+    // the last 3x3 tile is in registers, every LDS-DMA piece has landed).  One barrier per step, all 8 waves in step, each keeps its accumulator
+    // tiles.  The weight rows (BM x 128 bytes, L2-resident) are double-buffered and issued one step ahead; the tile's 256 pixel rows (32 KB per
+    // step, every byte of them from HBM: this loop is the launch's memory phase) go through a ring of THREE slots, issued two steps ahead, behind
+    // a counted wait that leaves the newest four pieces in flight.
     // The accumulators change units first: the two packed weights carry different powers of two (exact: a power-of-two ratio).
     static_assert(X3I, "skip fold: split precision only");
-    const int sC = kp.sk_c, nks = sC / BKE, su = kp.sk_up ? 1 : 0, Hs = H >> su, Ws = W >> su;
+    const int sC = kp.sk_c, nks = sC / BKE, su = kp.sk_up & 1, Hs = H >> su, Ws = W >> su;
     const float ratio = kp.sk_ratio;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] *= ratio;
-    constexpr int S_A = BM * 128, S_STAGE = S_A + BN * 128;
-    static_assert(2 * S_STAGE <= H_OFF + 2 * H_BUF, "skip fold: two stages fit the kernel's LDS");
+    constexpr int S_A = BM * 128, S_B = BN * 128, B_OFF = 2 * S_A;
+    static_assert(B_OFF + 3 * S_B <= H_OFF + 2 * H_BUF, "skip fold: the rings fit the kernel's LDS");
     // (readfirstlane: behind the loop hipcc keeps these uniform values in vector registers, which the LDS-DMA statement cannot take)
     dts_i32x4 rs_sw = make_rsrc(kp.sk_w, (uint32_t)((size_t)kp.cout * sC * ES));
     dts_i32x4 rs_sx = make_rsrc(kp.sk_x, (uint32_t)((size_t)kp.n * Hs * Ws * sC * ES));
@@ -1432,38 +1433,46 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
       const int pl = 8 * (w + 8 * j) + r0, y = y0 + (pl >> 4), x = x0 + (pl & 15);
       sbvo[j] = (uint32_t)(((img0 * Hs + (y >> su)) * Ws + (x >> su)) * sC) * ES + schunk;
     }
-    const uint32_t sa_dst = lds_base + (8 * w) * 128, sb_dst = lds_base + S_A + (8 * w) * 128;
-#define SK_ISSUE(kt_, stage_)                                                                                  \
+    const uint32_t sa_dst = lds_base + (8 * w) * 128, sb_dst = lds_base + B_OFF + (8 * w) * 128;
+#define SK_ISSUE_A(kt_, slot_)                                                                                 \
     {                                                                                                         \
-      const uint32_t so_ = (uint32_t)(kt_) * 128u, d_ = (uint32_t)(stage_) * S_STAGE;                          \
-      _Pragma("unroll") for (int j = 0; j < AJ; ++j) bdma16(savo[j], rs_sw, so_, sa_dst + d_ + j * (64 * 128)); \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) bdma16(sbvo[j], rs_sx, so_, sb_dst + d_ + j * (64 * 128));  \
+      const uint32_t so_ = (uint32_t)(kt_) * 128u, d_ = sa_dst + (uint32_t)(slot_) * S_A;                      \
+      _Pragma("unroll") for (int j = 0; j < AJ; ++j) bdma16(savo[j], rs_sw, so_, d_ + j * (64 * 128));         \
     }
-    SK_ISSUE(0, 0);
+#define SK_ISSUE_B(kt_, slot_)                                                                                 \
+    {                                                                                                         \
+      const uint32_t so_ = (uint32_t)(kt_) * 128u, d_ = sb_dst + (uint32_t)(slot_) * S_B;                      \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) bdma16(sbvo[j], rs_sx, so_, d_ + j * (64 * 128));          \
+    }
+    SK_ISSUE_A(0, 0);
+    SK_ISSUE_B(0, 0);
+    if (nks > 1) SK_ISSUE_B(1, 1);
+    int bs = 0;                                            // pixel ring slot of step kt (step kt + 2 goes into the slot step kt - 1 read)
 #pragma unroll 1
     for (int kt = 0; kt < nks; ++kt) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // landed: the weight rows and pixel rows of this step; in flight at most the four pixel pieces of the next one (the newest issued)
+      if (kt + 1 < nks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_barrier" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      const int stg = kt & 1;
-      const bool nxt = kt + 1 < nks;
-      if (grp == 0 && nxt) SK_ISSUE(kt + 1, stg ^ 1);
-      const char* sa = smem + stg * S_STAGE + (grp * GM) * 128;
-      const char* sb = smem + stg * S_STAGE + S_A;
+      const int as = kt & 1;
+      if (kt + 1 < nks) SK_ISSUE_A(kt + 1, as ^ 1);
+      if (kt + 2 < nks) SK_ISSUE_B(kt + 2, bs == 0 ? 2 : bs - 1);
+      const char* sa = smem + as * S_A + (grp * GM) * 128;
+      const char* sb = smem + B_OFF + bs * S_B;
+      bs = bs == 2 ? 0 : bs + 1;
       uint4 fa[MT], fb[NT], ga[MT], gb[NT], fs[MT];
+      // all 20 fragment reads go out at once, in the order the three MFMA groups need them (wh . hi first); no full wait: the compiler's counted
+      // lgkmcnt waits let the first group start when its operands are back
 #pragma unroll
-      for (int i = 0; i < NT; ++i) {
-        const int off = swz(wn * 64 + i * 16 + lrow, lq);
-        fb[i] = *reinterpret_cast<const uint4*>(sb + off);
-        gb[i] = *reinterpret_cast<const uint4*>(sb + (off ^ 64));
-      }
+      for (int i = 0; i < NT; ++i) fb[i] = *reinterpret_cast<const uint4*>(sb + swz(wn * 64 + i * 16 + lrow, lq));
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int off = swz(i * 16 + lrow, lq);
-        fa[i] = *reinterpret_cast<const uint4*>(sa + off);
-        ga[i] = *reinterpret_cast<const uint4*>(sa + (off ^ 64));
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + swz(i * 16 + lrow, lq));
+#pragma unroll
+      for (int i = 0; i < NT; ++i) gb[i] = *reinterpret_cast<const uint4*>(sb + (swz(wn * 64 + i * 16 + lrow, lq) ^ 64));
+#pragma unroll
+      for (int i = 0; i < MT; ++i) ga[i] = *reinterpret_cast<const uint4*>(sa + (swz(i * 16 + lrow, lq) ^ 64));
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < MT; ++i) fs[i] = f16x8_mul_2m11(fa[i]);
       __builtin_amdgcn_sched_barrier(0);
@@ -1482,9 +1491,9 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(const ConvP kp) {
         for (int j = 0; j < NT; ++j) Mma<T>::run(acc[i][j], ga[i], fb[j]);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
-      if (grp == 1 && nxt) SK_ISSUE(kt + 1, stg ^ 1);
     }
-#undef SK_ISSUE
+#undef SK_ISSUE_A
+#undef SK_ISSUE_B
   }
   __syncthreads();
   DTS_STAMP(2);
