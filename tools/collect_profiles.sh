@@ -62,9 +62,11 @@ try:      # the SAME profiled process measured both ways (final_profiles.sh: fin
     b = json.loads([l for l in open('gpurun_out/final_prof_both.json') if l.startswith('{')][-1])['roofline']
     import os
     rows2 = list(csv.DictReader(open(max(glob.glob('gpurun_out/final_prof_both/*/*kernel_stats.csv'), key=os.path.getmtime))))
-    dom2 = [x for x in rows2 if rp['kernel'] in x['Name']][0]
-    out['same_process'] = {'in_process_avg_launch_us': b['avg_launch_us'], 'rocprofv3_avg_launch_us': round(float(dom2['AverageNs']) / 1e3, 2),
-                           'ratio': round(float(dom2['AverageNs']) / 1e3 / b['avg_launch_us'], 4), 'frac_in_process': b['frac'],
+    names = [i_['name'] for i_ in rp.get('instantiations', [])] or [rp['kernel']]       # the family's instantiations (with / without the folded skip conv), launch-weighted
+    dom2 = [x for x in rows2 if any(n_ in x['Name'] for n_ in names)]
+    us2 = sum(float(x['TotalDurationNs']) for x in dom2) / sum(int(x['Calls']) for x in dom2) / 1e3
+    out['same_process'] = {'in_process_avg_launch_us': b['avg_launch_us'], 'rocprofv3_avg_launch_us': round(us2, 2),
+                           'ratio': round(us2 / b['avg_launch_us'], 4), 'frac_in_process': b['frac'],
                            'note': 'one process under rocprofv3: HIP events attached to the dispatches (eager launches of the instrumented steps) vs the trace average over ALL '
                                    'dispatches of that kernel in the process (graph replays + the instrumented eager steps)'}
 except Exception as e:

@@ -11,8 +11,9 @@ import os
 import json
 import sys
 
-PAT = {'bf16': 'conv_pp_kernel<bf16_t, 9, 0, false, 6, bf16_t>', 'f16': 'conv_pp_kernel<f16_t, 9, 0, false, 6, f16_t>',
-       'f16x3': 'conv_pp_kernel<f16_t, 9, 0, false, 6, float>'}
+# (name prefixes: the family spans the instantiations with and without the folded skip convolution, conv_pp_kernel<.., SK = false | true>)
+PAT = {'bf16': 'conv_pp_kernel<bf16_t, 9, 0, false, 6, bf16_t', 'f16': 'conv_pp_kernel<f16_t, 9, 0, false, 6, f16_t',
+       'f16x3': 'conv_pp_kernel<f16_t, 9, 0, false, 6, float'}
 
 
 def short(name):
@@ -35,8 +36,10 @@ def main():
     if not dom:          # older name form without the output-type argument
         dom = [r for r in rows if PAT[dtype].rsplit(',', 1)[0] in r['Name']]
     r = dom[0]
+    calls, ns = sum(int(x['Calls']) for x in dom), sum(float(x['TotalDurationNs']) for x in dom)          # launch-weighted over the family's instantiations
     doc = {'kernel_family': 'conv_pp_kernel', 'kernel': short(r['Name']), 'dtype': dtype,
-           'calls': int(r['Calls']), 'avg_launch_us': round(float(r['AverageNs']) / 1e3, 3), 'share_of_kernel_time': round(float(r['TotalDurationNs']) / tot, 4),
+           'instantiations': [{'name': short(x['Name']), 'calls': int(x['Calls']), 'avg_us': round(float(x['AverageNs']) / 1e3, 3)} for x in dom],
+           'calls': calls, 'avg_launch_us': round(ns / calls / 1e3, 3), 'share_of_kernel_time': round(ns / tot, 4),
            'collected_at_commit': commit, 'csrc_sha256': _digest(),
            'command': 'rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --dtype %s --no-cpu-baseline --no-kernel-timing --no-e2e --no-parity --no-subrecords' % dtype,
            'top_kernels': [{'name': short(x['Name'])[:90], 'calls': int(x['Calls']),

@@ -49,7 +49,7 @@ def main():
         line = f'{(n, hw, c, cs, cout, up)}: plain {med["plain"]:7.1f} us |'
         for v in variants:
             d = med[v] - med['plain']
-            line += f' skip loop {d:6.1f} us ({gf / d * 1e3:4.0f} TFLOP/s algorithmic, {gf * 1e9 / (n * hw * hw * cout) / 2 * (n * (hw // (2 if up else 1)) ** 2) * 4 / d / 1e6:5.2f} TB/s of skip operand)'
+            line += f' skip loop {d:6.1f} us ({gf / d * 1e3:4.0f} TFLOP/s algorithmic, operand read at {n * hs * hs * cs * 4 / d / 1e6:4.2f} TB/s)'
         _lib.set_tuning('conv_skip_fold', -1)
         print(line, flush=True)
 
