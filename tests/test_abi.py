@@ -25,6 +25,36 @@ def test_library_exports_every_declared_symbol():
     assert _lib.load().dts_version() == _lib.ABI_VERSION
 
 
+def test_which_launches_fold_the_skip_convolution():
+    """dts_conv_folds_skip is host logic only (shape, dtype, kernel choice): the policy table for an ADM ImageNet-64 denoiser forward, no GPU
+    needed.  At 64 rows the conv1 launches of the three ping-pong levels fold their block's 1x1 skip convolution (networks.py:164,177); the 8x8
+    level (implicit-GEMM kernel), every grid that would take a K split (an 8-row forward), the 16-bit modes and launches with a residual do not."""
+    from diffusion_tts_amd import _lib
+    lib = _lib.load()
+
+    def folds(n, hw, c, cout, skip_c, *, up=0, dtype=_lib.DTS_F16X3, residual=0, ksize=3, out_split2=0):
+        a = _lib.ConvArgs()
+        a.n, a.hin, a.win, a.c1, a.c2, a.cout, a.ksize, a.dtype = n, hw, hw, 2 * c, 0, cout, ksize, dtype
+        a.skip_c, a.skip_up, a.residual, a.out_split2 = skip_c, up, residual, out_split2
+        return lib.dts_conv_folds_skip(ctypes.byref(a))
+
+    assert folds(64, 64, 192, 192, 2 * 384) == 1            # decoder, 64x64: cat(192, 192) -> 192
+    assert folds(64, 32, 384, 384, 2 * 768) == 1            # decoder, 32x32
+    assert folds(64, 32, 384, 384, 2 * 192, up=0) == 1      # encoder, first block of the 384-wide level
+    assert folds(64, 16, 576, 576, 2 * 1152) == 1           # decoder, 16x16: exactly 192 blocks, no K split
+    assert folds(64, 32, 256, 256, 2 * 128) == 1            # classifier width: the 128-cout block form
+    assert folds(64, 8, 768, 768, 2 * 1536) == 0            # 8x8: implicit-GEMM kernel
+    assert folds(8, 64, 192, 192, 2 * 384) == 0             # one rank's 8 rows: that grid does not take the unsplit ping-pong kernel
+    assert folds(8, 32, 384, 384, 2 * 768) == 0             #   ... and this one takes a K split
+    assert folds(64, 64, 192, 192, 2 * 384, residual=1) == 0
+    assert folds(64, 64, 192, 192, 2 * 384, out_split2=1) == 0
+    assert folds(64, 64, 192, 192, 2 * 384, ksize=1) == 0
+    assert folds(64, 64, 192, 192, 384, dtype=_lib.DTS_BF16) == 0
+    assert folds(64, 64, 192, 192, 2 * 48) == 0             # 48 channels: not whole 32-channel K steps of 64 f16 elements
+    assert folds(64, 64, 192, 192, 0) == 0
+    assert lib.dts_conv_folds_skip(None) == 0
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, 'diffusion_tts_amd')
     for dp, _, files in os.walk(pkg):
